@@ -1,0 +1,79 @@
+// Shared helpers for the gfx950 kernels and the C ABI (no torch types anywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/mi355_nnunet.h"
+
+namespace mi355 {
+
+void set_error(const char *fmt, ...);
+
+#define MI355_HIP(expr)                                                                    \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            ::mi355::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),     \
+                               __FILE__, __LINE__);                                        \
+            return MI355_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+#define MI355_TRY(expr)            \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != MI355_OK)      \
+            return rc__;           \
+    } while (0)
+
+#define MI355_REQUIRE(cond, ...)              \
+    do {                                      \
+        if (!(cond)) {                        \
+            ::mi355::set_error(__VA_ARGS__);  \
+            return MI355_ERR_INVALID;         \
+        }                                     \
+    } while (0)
+
+// Exact unsigned division by a runtime constant for n < 2^31 (round-up method).
+struct FastDiv {
+    uint32_t d, m, s;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t s = 0;
+    while ((1u << s) < d)
+        ++s;
+    f.s = s;
+    f.m = (uint32_t)(((uint64_t(1) << 32) * ((uint64_t(1) << s) - d)) / d + 1);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
+    return (__umulhi(n, f.m) + n) >> f.s;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD one contiguous
+// range of the logical tile list so halo re-reads hit that XCD's L2.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+inline int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v)
+        ++l;
+    return l;
+}
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace mi355

@@ -1,0 +1,432 @@
+// 3x3x3 convolution, NDHWC fp32, as an implicit GEMM on the gfx950 matrix cores.
+//
+// Replaces torch.nn.Conv3d(k=3, p=1, stride 1|2) inside ConvDropoutNormNonlin
+// (reference model_architecture/generic_UNet.py:56,69) - 99.7 % of the path's flops.
+//
+// GEMM view:  M = output voxels, N = Cout, K = 27 taps x Cin.
+//   * A operand (voxels x channels) comes from an LDS-staged input halo brick of CC channels:
+//     one 16-B ds_read_b128 per lane feeds FOUR v_mfma_f32_32x32x2_f32 (lane l holds channels
+//     g*8 + 4*(l>>5) + j, j = 0..3, of voxel l&31; MFMA j contracts the channel pair
+//     {g*8+j, g*8+4+j}).  Voxel stride in LDS is CC+4 floats so that the 16 lanes of a
+//     ds_read_b128 group fall on 16 distinct 16-B slots (conflict-free for x-consecutive lanes).
+//   * B operand (weights) is pre-permuted on the host into exactly that fragment order, 1 KiB per
+//     (tap, 8-channel group, 32-cout fragment); every wave streams it with one global_load_dwordx4
+//     per lane (L2 resident: all workgroups read the same few hundred KB).
+//   * f32-input MFMA is an exact k-ordered fmaf chain (no TF32 on gfx950), so results differ from
+//     the CPU reference only by summation order.
+// Epilogue: + bias, optional LeakyReLU, predicated NDHWC store (one 128-B line per voxel and
+// 32-cout fragment), optional per-(n, channel) sum / sum-of-squares for Instance/GroupNorm
+// (wave reduction -> LDS -> one fp64 atomic per channel per workgroup).
+#include "kernels.h"
+
+#include <cstring>
+#include <vector>
+
+namespace mi355 {
+
+struct ConvArgs {
+    const float *in0, *in1;
+    const float *wp, *bias;
+    float *out;
+    double *stats;
+    int C0, C1;
+    int N, Di, Hi, Wi, Do, Ho, Wo, Cout;
+    int lx, ly, lz;  // log2 of the output tile dims
+    int tiles_x, tiles_y, tiles_z;
+    int IX, IY, IZ;  // input brick dims
+    FastDiv div_tiles_per_n, div_tiles_x, div_tiles_y, div_IX, div_IY;
+    int nchunks;
+    int act;
+    float slope;
+};
+
+template <int STRIDE, int CC, int MF, int NF>
+__global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int S = CC + 4;  // padded voxel stride in floats
+    constexpr int Q = CC / 4;  // 16-B pieces per voxel
+    constexpr int G = CC / 8;  // 8-channel groups per chunk
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int n = (int)fdiv((uint32_t)bid, p.div_tiles_per_n);
+    int t = bid - n * (int)p.div_tiles_per_n.d;
+    const int tzy = (int)fdiv((uint32_t)t, p.div_tiles_x);
+    const int tile_x = t - tzy * p.tiles_x;
+    const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
+    const int tile_y = tzy - tile_z * p.tiles_y;
+    const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
+    const int oz0 = tile_z << p.lz, oy0 = tile_y << p.ly, ox0 = tile_x << p.lx;
+    const int iz0 = oz0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+    const int IX = p.IX, IY = p.IY;
+    const int brickvox = IX * IY * p.IZ;
+    const int npieces = brickvox * Q;
+
+    // per-lane LDS base (floats) of each M fragment's voxel at tap (0,0,0)
+    int a_base[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int v = (wave * MF + mf) * 32 + l31;
+        const int x = v & TXm, y = (v >> p.lx) & TYm, z = v >> (p.lx + p.ly);
+        a_base[mf] = ((z * STRIDE * IY + y * STRIDE) * IX + x * STRIDE) * S + half * 4;
+    }
+
+    f32x16 acc[MF][NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[mf][nf][r] = 0.f;
+
+    const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * G * NF * 256) + lane * 4;
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        // ---- stage the CC-channel input halo brick (zero outside the volume)
+        const int cglob = ch * CC;
+        const float *src;
+        int Csrc, coff;
+        if (cglob < p.C0) {
+            src = p.in0; Csrc = p.C0; coff = cglob;
+        } else {
+            src = p.in1; Csrc = p.C1; coff = cglob - p.C0;
+        }
+        src += (size_t)n * p.Di * p.Hi * p.Wi * Csrc + coff;
+        constexpr int U = 4;
+        for (int i0 = tid; i0 < npieces; i0 += 256 * U) {
+            f32x4 v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256;
+                const int bv = i / Q, q = i - bv * Q;
+                const int r = (int)fdiv((uint32_t)bv, p.div_IX);
+                const int bx = bv - r * IX;
+                const int bz = (int)fdiv((uint32_t)r, p.div_IY);
+                const int by = r - bz * IY;
+                const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+                const bool ok = (i < npieces) && ((unsigned)iz < (unsigned)p.Di) &&
+                                ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
+                dst[u] = (i < npieces) ? bv * S + q * 4 : -1;
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (ok)
+                    val = *(const f32x4 *)(src + ((size_t)(iz * p.Hi + iy) * p.Wi + ix) * Csrc + q * 4);
+                v[u] = val;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0)
+                    *(f32x4 *)(lds + dst[u]) = v[u];
+        }
+        __syncthreads();
+
+        // ---- 27 taps x G channel groups, fragments prefetched one step ahead
+        const float *wch = wblk + (size_t)ch * (27 * G * NF * 256);
+        f32x4 a_cur[MF], b_cur[NF], a_nxt[MF], b_nxt[NF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+            a_cur[mf] = *(const f32x4 *)(lds + a_base[mf]);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+            b_cur[nf] = *(const f32x4 *)(wch + nf * 256);
+
+        for (int tap = 0; tap < 27; ++tap) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                // next step = (tap, g+1) or (tap+1, 0)
+                int ntap = tap, ng = g + 1;
+                if (ng == G) { ng = 0; ntap = tap + 1; }
+                if (ntap < 27) {
+                    const int dz = ntap / 9, rr = ntap - dz * 9, dy = rr / 3, dx = rr - dy * 3;
+                    const int off = ((dz * IY + dy) * IX + dx) * S + ng * 8;
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf)
+                        a_nxt[mf] = *(const f32x4 *)(lds + a_base[mf] + off);
+                    const float *wn = wch + (size_t)(ntap * G + ng) * (NF * 256);
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf)
+                        b_nxt[nf] = *(const f32x4 *)(wn + nf * 256);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf)
+                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mf][j], b_cur[nf][j],
+                                                                               acc[mf][nf], 0, 0, 0);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+                    a_cur[mf] = a_nxt[mf];
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+                    b_cur[nf] = b_nxt[nf];
+            }
+        }
+        __syncthreads();  // brick is overwritten by the next chunk
+    }
+
+    // ---- epilogue.  C/D map of 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float s1[NF], s2[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        s1[nf] = 0.f; s2[nf] = 0.f;
+    }
+    const int co_blk = (int)blockIdx.y * NF * 32;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int v = (wave * MF + mf) * 32 + row;
+            const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
+            const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
+            float *orow = p.out + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + l31;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                float val = acc[mf][nf][r] + (p.bias ? p.bias[co_blk + nf * 32 + l31] : 0.f);
+                if (p.act == ACT_LRELU)
+                    val = val > 0.f ? val : val * p.slope;
+                if (ok) {
+                    orow[nf * 32] = val;
+                    s1[nf] += val;
+                    s2[nf] += val * val;
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        // lanes l and l+32 hold the same channel
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            s1[nf] += __shfl_xor(s1[nf], 32);
+            s2[nf] += __shfl_xor(s2[nf], 32);
+        }
+        float *red = lds;  // [4 waves][NF*32][2]; the brick is dead (barrier above)
+        if (half == 0) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                red[(wave * NF * 32 + nf * 32 + l31) * 2 + 0] = s1[nf];
+                red[(wave * NF * 32 + nf * 32 + l31) * 2 + 1] = s2[nf];
+            }
+        }
+        __syncthreads();
+        if (tid < NF * 32 * 2) {
+            const int c = tid >> 1, k = tid & 1;
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                tot += (double)red[(w * NF * 32 + c) * 2 + k];
+            atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, tot);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ direct kernel (any shape)
+// One thread per (voxel, cout); used for shapes the MFMA path does not cover and as an
+// independent on-device cross-check of it in the parity tests.
+__global__ void conv3_direct_kernel(const float *in0, const float *in1, int C0, int C1, const float *w,
+                                    const float *bias, float *out, double *stats, int N, int Di, int Hi,
+                                    int Wi, int Do, int Ho, int Wo, int Cout, int stride, int act,
+                                    float slope) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)N * Do * Ho * Wo * Cout;
+    if (idx >= total)
+        return;
+    const int co = (int)(idx % Cout);
+    size_t v = idx / Cout;
+    const int ox = (int)(v % Wo); v /= Wo;
+    const int oy = (int)(v % Ho); v /= Ho;
+    const int oz = (int)(v % Do);
+    const int n = (int)(v / Do);
+    const int Cin = C0 + C1;
+    float acc = 0.f;
+    for (int dz = 0; dz < 3; ++dz) {
+        const int iz = oz * stride - 1 + dz;
+        if ((unsigned)iz >= (unsigned)Di) continue;
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * stride - 1 + dy;
+            if ((unsigned)iy >= (unsigned)Hi) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * stride - 1 + dx;
+                if ((unsigned)ix >= (unsigned)Wi) continue;
+                const size_t vox = (((size_t)n * Di + iz) * Hi + iy) * Wi + ix;
+                const int tap = (dz * 3 + dy) * 3 + dx;
+                for (int c = 0; c < C0; ++c)
+                    acc = fmaf(in0[vox * C0 + c], w[((size_t)co * Cin + c) * 27 + tap], acc);
+                for (int c = 0; c < C1; ++c)
+                    acc = fmaf(in1[vox * C1 + c], w[((size_t)co * Cin + C0 + c) * 27 + tap], acc);
+            }
+        }
+    }
+    float val = acc + (bias ? bias[co] : 0.f);
+    if (act == ACT_LRELU)
+        val = val > 0.f ? val : val * slope;
+    out[idx] = val;
+    if (stats) {
+        atomicAdd(stats + ((size_t)n * Cout + co) * 2 + 0, (double)val);
+        atomicAdd(stats + ((size_t)n * Cout + co) * 2 + 1, (double)val * (double)val);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+// Packed layout (floats): [cout_block][chunk][tap][g][nf][lane 0..63][j 0..3] with
+//   cout = (cout_block*NF + nf)*32 + (lane&31),  cin = chunk*CC + g*8 + (lane>>5)*4 + j.
+static void pack_conv_weights_f32(const float *w, int cin, int cin_pad, int cout, int cc, int nf,
+                                  std::vector<float> &out) {
+    const int nchunks = cin_pad / cc, G = cc / 8, nblk = cout / (32 * nf);
+    out.assign((size_t)nblk * nchunks * 27 * G * nf * 256, 0.f);
+    size_t o = 0;
+    for (int b = 0; b < nblk; ++b)
+        for (int ch = 0; ch < nchunks; ++ch)
+            for (int tap = 0; tap < 27; ++tap)
+                for (int g = 0; g < G; ++g)
+                    for (int f = 0; f < nf; ++f)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j, ++o) {
+                                const int co = (b * nf + f) * 32 + (lane & 31);
+                                const int ci = ch * cc + g * 8 + (lane >> 5) * 4 + j;
+                                out[o] = (ci < cin) ? w[((size_t)co * cin + ci) * 27 + tap] : 0.f;
+                            }
+}
+
+int conv_weights_upload(const float *w_host, const float *bias_host, int cin, int cin_pad, int cout,
+                        int stride, bool keep_plain, ConvWeights *out) {
+    MI355_REQUIRE(stride == 1 || stride == 2, "conv stride %d unsupported", stride);
+    MI355_REQUIRE(cin_pad >= cin && cin_pad % 4 == 0, "bad cin_pad %d for cin %d", cin_pad, cin);
+    ConvWeights cw;
+    cw.cin = cin; cw.cin_pad = cin_pad; cw.cout = cout; cw.stride = stride;
+    const bool mfma_ok = (cout % 32 == 0) && (cin_pad % 8 == 0);
+    if (mfma_ok) {
+        // stride 2 bricks are ~8x the output tile: keep them to 8 channels per pass
+        cw.cc = (stride == 1 && cin_pad % 16 == 0) ? 16 : 8;
+        cw.nf = (cout % 64 == 0) ? 2 : 1;
+        std::vector<float> packed;
+        pack_conv_weights_f32(w_host, cin, cin_pad, cout, cw.cc, cw.nf, packed);
+        cw.wp_bytes = packed.size() * sizeof(float);
+        MI355_HIP(hipMalloc(&cw.wp_dev, cw.wp_bytes));
+        MI355_HIP(hipMemcpy(cw.wp_dev, packed.data(), cw.wp_bytes, hipMemcpyHostToDevice));
+    }
+    if (keep_plain || !mfma_ok) {
+        // the direct kernel indexes channels of the (possibly zero-padded) input tensors
+        std::vector<float> plain((size_t)cout * cin_pad * 27, 0.f);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                memcpy(&plain[((size_t)co * cin_pad + ci) * 27], &w_host[((size_t)co * cin + ci) * 27],
+                       27 * sizeof(float));
+        MI355_HIP(hipMalloc(&cw.w_plain_dev, plain.size() * sizeof(float)));
+        MI355_HIP(hipMemcpy(cw.w_plain_dev, plain.data(), plain.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    MI355_HIP(hipMalloc(&cw.bias_dev, cout * sizeof(float)));
+    if (bias_host)
+        MI355_HIP(hipMemcpy(cw.bias_dev, bias_host, cout * sizeof(float), hipMemcpyHostToDevice));
+    else
+        MI355_HIP(hipMemset(cw.bias_dev, 0, cout * sizeof(float)));
+    *out = cw;
+    return MI355_OK;
+}
+
+void conv_weights_free(ConvWeights *w) {
+    if (w->wp_dev) (void)hipFree(w->wp_dev);
+    if (w->bias_dev) (void)hipFree(w->bias_dev);
+    if (w->w_plain_dev) (void)hipFree(w->w_plain_dev);
+    *w = ConvWeights();
+}
+
+// Output tile (power-of-two dims, 128*MF voxels): x as long as the volume allows (up to 32:
+// x-consecutive lanes are the conflict-free LDS pattern and give the longest contiguous global
+// rows), then the (y, z) split with the smallest input brick.
+static void choose_tile(int Do, int Ho, int Wo, int stride, int voxels, int *lz, int *ly, int *lx) {
+    auto p2cap = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    const int cz = p2cap(Do), cy = p2cap(Ho), cx = p2cap(Wo);
+    const int L = ilog2_exact(voxels);
+    int x = cx < 5 ? cx : 5;
+    if (x > L) x = L;
+    long best = -1;
+    int bz = L - x, by = 0;
+    for (int y = 0; x + y <= L; ++y) {
+        const int z = L - x - y;
+        const int oy = y > cy ? y - cy : 0, oz = z > cz ? z - cz : 0;  // lanes wasted past the volume
+        const long brick = (long)(((1 << y) - 1) * stride + 3) * (((1 << z) - 1) * stride + 3);
+        const long cost = ((long)(oy + oz) << 32) + brick;
+        if (best < 0 || cost < best) {
+            best = cost; bz = z; by = y;
+        }
+    }
+    *lz = bz; *ly = by; *lx = x;
+}
+
+template <int STRIDE, int CC, int MF, int NF>
+static int launch_conv(const ConvArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s) {
+    auto kern = conv3_f32_mfma_kernel<STRIDE, CC, MF, NF>;
+    static size_t attr_bytes = 48 * 1024;  // raise the dynamic-LDS limit on demand (one process per GPU)
+    if (lds_bytes > attr_bytes) {
+        MI355_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_bytes = lds_bytes;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, a);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s) {
+    MI355_REQUIRE(w.wp_dev != nullptr, "conv %d->%d has no MFMA weight pack", w.cin, w.cout);
+    MI355_REQUIRE(c.C0 + c.C1 == w.cin_pad, "conv input channels %d+%d != %d", c.C0, c.C1, w.cin_pad);
+    MI355_REQUIRE(c.C0 % w.cc == 0 && c.C1 % w.cc == 0, "concat split %d/%d not a multiple of %d", c.C0, c.C1, w.cc);
+    MI355_REQUIRE(c.C1 == 0 || c.in1 != nullptr, "second conv input missing");
+    ConvArgs a;
+    a.in0 = c.in0; a.in1 = c.in1; a.C0 = c.C0; a.C1 = c.C1;
+    a.wp = w.wp_dev; a.bias = w.bias_dev; a.out = c.out; a.stats = c.stats;
+    a.N = c.N; a.Di = c.Di; a.Hi = c.Hi; a.Wi = c.Wi;
+    const int st = w.stride;
+    a.Do = (c.Di - 1) / st + 1; a.Ho = (c.Hi - 1) / st + 1; a.Wo = (c.Wi - 1) / st + 1;  // k=3, p=1
+    a.Cout = w.cout;
+    const int MF = (st == 1) ? 2 : 1;
+    choose_tile(a.Do, a.Ho, a.Wo, st, 128 * MF, &a.lz, &a.ly, &a.lx);
+    const int TX = 1 << a.lx, TY = 1 << a.ly, TZ = 1 << a.lz;
+    a.tiles_x = ceil_div(a.Wo, TX); a.tiles_y = ceil_div(a.Ho, TY); a.tiles_z = ceil_div(a.Do, TZ);
+    a.IX = (TX - 1) * st + 3; a.IY = (TY - 1) * st + 3; a.IZ = (TZ - 1) * st + 3;
+    const int tiles_per_n = a.tiles_x * a.tiles_y * a.tiles_z;
+    a.div_tiles_per_n = make_fastdiv(tiles_per_n);
+    a.div_tiles_x = make_fastdiv(a.tiles_x);
+    a.div_tiles_y = make_fastdiv(a.tiles_y);
+    a.div_IX = make_fastdiv(a.IX);
+    a.div_IY = make_fastdiv(a.IY);
+    a.nchunks = w.cin_pad / w.cc;
+    a.act = c.act; a.slope = c.slope;
+    const size_t brick_bytes = (size_t)a.IX * a.IY * a.IZ * (w.cc + 4) * sizeof(float);
+    const size_t lds_bytes = brick_bytes < 4096 ? 4096 : brick_bytes;  // >= the stats scratch
+    MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
+    MI355_REQUIRE((long)tiles_per_n * c.N < (1l << 30), "conv grid too large");
+    dim3 grid(tiles_per_n * c.N, w.cout / (32 * w.nf));
+    if (st == 1 && w.cc == 16 && w.nf == 1) return launch_conv<1, 16, 2, 1>(a, grid, lds_bytes, s);
+    if (st == 1 && w.cc == 16 && w.nf == 2) return launch_conv<1, 16, 2, 2>(a, grid, lds_bytes, s);
+    if (st == 1 && w.cc == 8 && w.nf == 1) return launch_conv<1, 8, 2, 1>(a, grid, lds_bytes, s);
+    if (st == 1 && w.cc == 8 && w.nf == 2) return launch_conv<1, 8, 2, 2>(a, grid, lds_bytes, s);
+    if (st == 2 && w.cc == 8 && w.nf == 1) return launch_conv<2, 8, 1, 1>(a, grid, lds_bytes, s);
+    if (st == 2 && w.cc == 8 && w.nf == 2) return launch_conv<2, 8, 1, 2>(a, grid, lds_bytes, s);
+    set_error("no conv kernel for stride %d cc %d nf %d", st, w.cc, w.nf);
+    return MI355_ERR_UNSUPPORTED;
+}
+
+int conv3d_direct_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s) {
+    MI355_REQUIRE(w.w_plain_dev != nullptr, "conv %d->%d has no plain weights", w.cin, w.cout);
+    MI355_REQUIRE(c.C0 + c.C1 == w.cin_pad, "conv input channels %d+%d != %d", c.C0, c.C1, w.cin_pad);
+    const int st = w.stride;
+    const int Do = (c.Di - 1) / st + 1, Ho = (c.Hi - 1) / st + 1, Wo = (c.Wi - 1) / st + 1;
+    const size_t total = (size_t)c.N * Do * Ho * Wo * w.cout;
+    const size_t blocks = (total + 255) / 256;
+    MI355_REQUIRE(blocks < (1ull << 31), "direct conv grid too large");
+    hipLaunchKernelGGL(conv3_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, s, c.in0, c.in1, c.C0, c.C1,
+                       w.w_plain_dev, w.bias_dev, c.out, c.stats, c.N, c.Di, c.Hi, c.Wi, Do, Ho, Wo, w.cout, st,
+                       c.act, c.slope);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+}  // namespace mi355

@@ -1,0 +1,499 @@
+// HBM-bound kernels around the convolutions: norm finalize/apply, tile gather with mirror
+// flips, the 1x1x1 segmentation head fused with sigmoid/softmax + mirror flip-back +
+// Gaussian-weighted scatter-add, probability finish, region thresholding, label ensemble and
+// the masked z-score.  All accesses are 16 B per lane where the layout allows it.
+#include "kernels.h"
+
+#include <vector>
+
+namespace mi355 {
+
+// ------------------------------------------------------------------ Instance / Group norm
+// Finalises the (sum, sum^2) the conv epilogue accumulated into per-(n, channel) affine
+// coefficients: y = x*scale + shift.  Replaces the statistics half of
+// nn.InstanceNorm3d / nn.GroupNorm (reference generic_UNet.py:62-65,72); biased variance, eps
+// inside the sqrt, as torch does.
+__global__ void norm_finalize_kernel(const double *stats, int N, int C, double count, int kind, int groups,
+                                     float eps, const float *gamma, const float *beta, float *scale,
+                                     float *shift) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * C)
+        return;
+    const int n = idx / C, c = idx - n * C;
+    double s1, s2, cnt;
+    if (kind == MI355_NORM_GROUP) {
+        const int cpg = C / groups, g0 = (c / cpg) * cpg;
+        s1 = 0.0; s2 = 0.0;
+        for (int k = 0; k < cpg; ++k) {
+            s1 += stats[((size_t)n * C + g0 + k) * 2 + 0];
+            s2 += stats[((size_t)n * C + g0 + k) * 2 + 1];
+        }
+        cnt = count * cpg;
+    } else {
+        s1 = stats[(size_t)idx * 2 + 0];
+        s2 = stats[(size_t)idx * 2 + 1];
+        cnt = count;
+    }
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    scale[idx] = (float)(g * rstd);
+    shift[idx] = (float)(b - mean * rstd * g);
+}
+
+int norm_finalize(const double *stats, int N, int C, int64_t count, int kind, int groups, float eps,
+                  const float *gamma, const float *beta, float *scale, float *shift, hipStream_t s) {
+    MI355_REQUIRE(kind != MI355_NORM_GROUP || (groups > 0 && C % groups == 0), "GroupNorm: %d channels, %d groups", C, groups);
+    const int total = N * C;
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, stats, N, C,
+                       (double)count, kind, groups, eps, gamma, beta, scale, shift);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+__global__ void norm_apply_kernel(f32x4 *x, int64_t total4, int64_t VC4, int C4, const f32x4 *scale,
+                                  const f32x4 *shift, int act, float slope) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / VC4;
+        const int c4 = (int)(i % C4);
+        const f32x4 sc = scale[n * C4 + c4], sh = shift[n * C4 + c4];
+        f32x4 v = x[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float y = v[k] * sc[k] + sh[k];
+            if (act == ACT_LRELU)
+                y = y > 0.f ? y : y * slope;
+            v[k] = y;
+        }
+        x[i] = v;
+    }
+}
+
+int norm_apply(float *x, int N, int64_t V, int C, const float *scale, const float *shift, int act,
+               float slope, hipStream_t s) {
+    MI355_REQUIRE(C % 4 == 0, "norm_apply: C=%d", C);
+    const int64_t total4 = (int64_t)N * V * C / 4;
+    int64_t blocks = (total4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (f32x4 *)x, total4,
+                       V * C / 4, C / 4, (const f32x4 *)scale, (const f32x4 *)shift, act, slope);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+// ------------------------------------------------------------------ tile gather (+ mirror flips)
+// Replaces the patch slicing of nnU-Net v1 `_internal_predict_3D_3Dconv_tiled` and the
+// torch.flip of `_internal_maybe_mirror_and_pred_3D`: sample b is the
+// tile at tiles[b].{z0,y0,x0} of the zero-padded volume, flipped along the axes in its mirror mask.
+constexpr int MAX_SAMPLES = 64;
+struct TileList {
+    TileDesc t[MAX_SAMPLES];
+};
+
+__global__ void extract_tiles_kernel(const float *vol, int C, int Z, int Y, int X, int padz, int pady,
+                                     int padx, TileList tl, int P0, int P1, int P2, int Cpad, float *x) {
+    const int b = blockIdx.y;
+    const TileDesc td = tl.t[b];
+    const int64_t PV = (int64_t)P0 * P1 * P2;
+    const int64_t ZYX = (int64_t)Z * Y * X;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < PV; v += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(v % P2);
+        const int py = (int)((v / P2) % P1);
+        const int pz = (int)(v / ((int64_t)P2 * P1));
+        const int sz = (td.mirror & 1) ? P0 - 1 - pz : pz;
+        const int sy = (td.mirror & 2) ? P1 - 1 - py : py;
+        const int sx = (td.mirror & 4) ? P2 - 1 - px : px;
+        const int gz = td.z0 + sz - padz, gy = td.y0 + sy - pady, gx = td.x0 + sx - padx;
+        const bool ok = (unsigned)gz < (unsigned)Z && (unsigned)gy < (unsigned)Y && (unsigned)gx < (unsigned)X;
+        float *dst = x + ((int64_t)b * PV + v) * Cpad;
+        const int64_t g = ((int64_t)gz * Y + gy) * X + gx;
+        for (int c = 0; c < Cpad; ++c)
+            dst[c] = (ok && c < C) ? vol[c * ZYX + g] : 0.f;
+    }
+}
+
+int extract_tiles(const float *vol, int C, int Z, int Y, int X, int padz, int pady, int padx,
+                  const TileDesc *tiles_host, int n_samples, int P0, int P1, int P2, int Cpad, float *x,
+                  hipStream_t s) {
+    MI355_REQUIRE(n_samples > 0 && n_samples <= MAX_SAMPLES, "extract_tiles: %d samples (max %d)", n_samples, MAX_SAMPLES);
+    TileList tl;
+    for (int i = 0; i < n_samples; ++i) tl.t[i] = tiles_host[i];
+    const int64_t PV = (int64_t)P0 * P1 * P2;
+    int64_t bx = (PV + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(extract_tiles_kernel, dim3((unsigned)bx, n_samples), dim3(256), 0, s, vol, C, Z, Y, X,
+                       padz, pady, padx, tl, P0, P1, P2, Cpad, x);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+__global__ void nchw_to_ndhwc_kernel(const float *x, int C, int64_t V, int Cpad, float *y, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / V, v = i - n * V;
+        for (int c = 0; c < Cpad; ++c)
+            y[i * Cpad + c] = c < C ? x[(n * C + c) * V + v] : 0.f;
+    }
+}
+
+int nchw_to_ndhwc(const float *x, int N, int C, int64_t V, int Cpad, float *y, hipStream_t s) {
+    const int64_t total = (int64_t)N * V;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(nchw_to_ndhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, C, V, Cpad, y, total);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+// ------------------------------------------------------------------ segmentation head
+int head_weights_upload(const float *w_host, const float *b_host, int cin, int ncls, HeadWeights *out) {
+    MI355_REQUIRE(ncls >= 1 && ncls <= 8, "head: %d classes unsupported (max 8)", ncls);
+    MI355_REQUIRE(cin % 4 == 0, "head: cin %d not a multiple of 4", cin);
+    HeadWeights h;
+    h.cin = cin; h.ncls = ncls;
+    MI355_HIP(hipMalloc(&h.w_dev, (size_t)ncls * cin * sizeof(float)));
+    MI355_HIP(hipMemcpy(h.w_dev, w_host, (size_t)ncls * cin * sizeof(float), hipMemcpyHostToDevice));
+    MI355_HIP(hipMalloc(&h.b_dev, 8 * sizeof(float)));
+    MI355_HIP(hipMemset(h.b_dev, 0, 8 * sizeof(float)));
+    if (b_host)
+        MI355_HIP(hipMemcpy(h.b_dev, b_host, ncls * sizeof(float), hipMemcpyHostToDevice));
+    *out = h;
+    return MI355_OK;
+}
+
+void head_weights_free(HeadWeights *w) {
+    if (w->w_dev) (void)hipFree(w->w_dev);
+    if (w->b_dev) (void)hipFree(w->b_dev);
+    *w = HeadWeights();
+}
+
+constexpr int HEAD_MAX_CLS = 8;
+
+// 8 lanes cooperate on one voxel: each takes every 8th 16-B channel quad, partial dot products
+// are combined with three xor-shuffles.  Returns the logits in every lane of the group.
+__device__ __forceinline__ void head_dot(const float *feat_vox, const float *w, const float *b, int C,
+                                         int ncls, int q, float *logit) {
+    float part[HEAD_MAX_CLS];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) part[k] = 0.f;
+    for (int c4 = q; c4 * 4 < C; c4 += 8) {
+        const f32x4 f = *(const f32x4 *)(feat_vox + c4 * 4);
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_CLS; ++k)
+            if (k < ncls) {
+                const f32x4 wk = *(const f32x4 *)(w + k * C + c4 * 4);
+                part[k] += f[0] * wk[0] + f[1] * wk[1] + f[2] * wk[2] + f[3] * wk[3];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) {
+        float v = part[k];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        logit[k] = v + (k < ncls ? b[k] : 0.f);
+    }
+}
+
+__global__ void head_logits_kernel(const float *feat, const float *w, const float *b, int C, int ncls,
+                                   int64_t V, int64_t total, float *logits) {
+    const int q = threadIdx.x & 7;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < total;
+         i += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        float lg[HEAD_MAX_CLS];
+        head_dot(feat + i * C, w, b, C, ncls, q, lg);
+        const int64_t n = i / V, v = i - n * V;
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_CLS; ++k)
+            if (k == q && k < ncls)
+                logits[(n * ncls + k) * V + v] = lg[k];
+    }
+}
+
+int head_logits(const HeadWeights &w, const float *feat, int N, int64_t V, float *logits, hipStream_t s) {
+    const int64_t total = (int64_t)N * V;
+    MI355_REQUIRE(total % 32 == 0, "head_logits: voxel count %ld not a multiple of 32", (long)total);
+    int64_t blocks = (total * 8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(head_logits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, feat, w.w_dev, w.b_dev,
+                       w.cin, w.ncls, V, total, logits);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+struct MirrorList {
+    int n;
+    int m[8];
+};
+
+// Replaces for ONE tile:
+//   result = sum_m  mult * flip_back(nonlin(net(flip_m(x))))      mult = 1/n_mirrors, m in list order
+//   result *= gaussian ; aggregated[:, tile] += result ; normaliser[tile] += gaussian
+// feat holds the last decoder feature map of the n_mirrors forwards of this tile.
+__global__ void head_aggregate_kernel(const float *feat, const float *w, const float *b, int C, int ncls,
+                                      MirrorList ml, int P0, int P1, int P2, int nonlin, const float *gauss,
+                                      float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0) {
+    const int q = threadIdx.x & 7;
+    const int64_t PV = (int64_t)P0 * P1 * P2;
+    const int64_t ZYXp = (int64_t)Zp * Yp * Xp;
+    const float mult = 1.0f / (float)ml.n;
+    for (int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; v < PV;
+         v += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        const int px = (int)(v % P2);
+        const int py = (int)((v / P2) % P1);
+        const int pz = (int)(v / ((int64_t)P2 * P1));
+        float res[HEAD_MAX_CLS];
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_CLS; ++k) res[k] = 0.f;
+        for (int mi = 0; mi < ml.n; ++mi) {
+            const int m = ml.m[mi];
+            const int sz = (m & 1) ? P0 - 1 - pz : pz;
+            const int sy = (m & 2) ? P1 - 1 - py : py;
+            const int sx = (m & 4) ? P2 - 1 - px : px;
+            const int64_t sv = ((int64_t)sz * P1 + sy) * P2 + sx;
+            float lg[HEAD_MAX_CLS];
+            head_dot(feat + ((int64_t)mi * PV + sv) * C, w, b, C, ncls, q, lg);
+            if (nonlin == MI355_NONLIN_SIGMOID) {
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_CLS; ++k) lg[k] = 1.0f / (1.0f + expf(-lg[k]));
+            } else if (nonlin == MI355_NONLIN_SOFTMAX) {
+                float mx = lg[0];
+#pragma unroll
+                for (int k = 1; k < HEAD_MAX_CLS; ++k) if (k < ncls) mx = fmaxf(mx, lg[k]);
+                float den = 0.f;
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) { lg[k] = expf(lg[k] - mx); den += lg[k]; }
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_CLS; ++k) lg[k] = lg[k] / den;
+            }
+#pragma unroll
+            for (int k = 0; k < HEAD_MAX_CLS; ++k) res[k] += mult * lg[k];
+        }
+        const float g = gauss ? gauss[v] : 1.0f;
+        const int64_t gi = ((int64_t)(z0 + pz) * Yp + (y0 + py)) * Xp + (x0 + px);
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_CLS; ++k)
+            if (k == q && k < ncls)
+                agg[k * ZYXp + gi] += res[k] * g;
+        if (cnt && q == 7)
+            cnt[gi] += g;
+    }
+}
+
+int head_aggregate(const HeadWeights &w, const float *feat, int first_sample, const int *mirrors_host,
+                   int n_mirrors, int P0, int P1, int P2, int nonlin, const float *gauss, float *agg,
+                   float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, hipStream_t s) {
+    MI355_REQUIRE(n_mirrors >= 1 && n_mirrors <= 8, "head_aggregate: %d mirrors", n_mirrors);
+    MI355_REQUIRE(w.ncls <= 7, "head_aggregate: %d classes (max 7)", w.ncls);
+    MirrorList ml;
+    ml.n = n_mirrors;
+    for (int i = 0; i < 8; ++i) ml.m[i] = i < n_mirrors ? mirrors_host[i] : 0;
+    const int64_t PV = (int64_t)P0 * P1 * P2;
+    MI355_REQUIRE(PV % 32 == 0, "head_aggregate: patch voxels %ld not a multiple of 32", (long)PV);
+    int64_t blocks = (PV * 8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(head_aggregate_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       feat + (size_t)first_sample * PV * w.cin, w.w_dev, w.b_dev, w.cin, w.ncls, ml, P0, P1, P2,
+                       nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+// class_probabilities = aggregated / normaliser, cropped back from the padded grid.
+__global__ void finish_probs_kernel(const float *agg, const float *cnt, int C, int Z, int Y, int X, int Zp,
+                                    int Yp, int Xp, int pz, int py, int px, float *probs, int accumulate) {
+    const int64_t ZYX = (int64_t)Z * Y * X, ZYXp = (int64_t)Zp * Yp * Xp;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < ZYX; v += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(v % X);
+        const int y = (int)((v / X) % Y);
+        const int z = (int)(v / ((int64_t)X * Y));
+        const int64_t gi = ((int64_t)(z + pz) * Yp + (y + py)) * Xp + (x + px);
+        const float c = cnt[gi];
+        for (int k = 0; k < C; ++k) {
+            const float p = agg[k * ZYXp + gi] / c;
+            if (accumulate)
+                probs[k * ZYX + v] += p;
+            else
+                probs[k * ZYX + v] = p;
+        }
+    }
+}
+
+int finish_probs(const float *agg, const float *cnt, int C, int Z, int Y, int X, int Zp, int Yp, int Xp,
+                 int pz, int py, int px, float *probs, int accumulate, hipStream_t s) {
+    const int64_t ZYX = (int64_t)Z * Y * X;
+    int64_t blocks = (ZYX + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(finish_probs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, agg, cnt, C, Z, Y, X, Zp, Yp,
+                       Xp, pz, py, px, probs, accumulate);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+__global__ void cnt_add_tile_kernel(const float *gauss, int P0, int P1, int P2, float *cnt, int Yp, int Xp, int z0,
+                                    int y0, int x0) {
+    const int64_t PV = (int64_t)P0 * P1 * P2;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < PV; v += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(v % P2);
+        const int py = (int)((v / P2) % P1);
+        const int pz = (int)(v / ((int64_t)P2 * P1));
+        cnt[((int64_t)(z0 + pz) * Yp + (y0 + py)) * Xp + (x0 + px)] += gauss ? gauss[v] : 1.0f;
+    }
+}
+
+int cnt_add_tile(const float *gauss, int P0, int P1, int P2, float *cnt, int Yp, int Xp, int z0, int y0, int x0,
+                 hipStream_t s) {
+    const int64_t PV = (int64_t)P0 * P1 * P2;
+    int64_t blocks = (PV + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cnt_add_tile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gauss, P0, P1, P2, cnt, Yp, Xp,
+                       z0, y0, x0);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+__global__ void scale_kernel(float *x, int64_t n, float divisor) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = x[i] / divisor;
+}
+
+int scale_inplace(float *x, int64_t n, float divisor, hipStream_t s) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, divisor);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+// ------------------------------------------------------------------ export / ensemble / preprocess
+struct OrderList {
+    int v[8];
+};
+
+__global__ void regions_to_labels_kernel(const float *probs, int C, int Z, int Y, int X, OrderList order,
+                                         int bz, int by, int bx, int FY, int FX, uint8_t *labels) {
+    const int64_t ZYX = (int64_t)Z * Y * X;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < ZYX; v += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(v % X);
+        const int y = (int)((v / X) % Y);
+        const int z = (int)(v / ((int64_t)X * Y));
+        int lab = 0;
+        for (int k = 0; k < C; ++k)
+            if (probs[k * ZYX + v] > 0.5f)
+                lab = order.v[k];
+        labels[((int64_t)(z + bz) * FY + (y + by)) * FX + (x + bx)] = (uint8_t)lab;
+    }
+}
+
+__global__ void label_ensemble_kernel(const uint8_t *a, const uint8_t *b, uint8_t *out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        // np.round((a+b)/2.0): halves round to the even neighbour
+        const int s = (int)a[i] + (int)b[i];
+        int r = s >> 1;
+        if ((s & 1) && (r & 1))
+            r += 1;
+        out[i] = (uint8_t)r;
+    }
+}
+
+__global__ void prob_mean_kernel(const float *a, const float *b, float *out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (a[i] + b[i]) / 2.0f;
+}
+
+// masked z-score: two launches per call (sums, then apply) over C channels.
+__global__ void masked_sums_kernel(const float *vol, const uint8_t *mask, int64_t V, double *sums) {
+    const int c = blockIdx.y;
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x)
+        if (mask[i]) {
+            const double x = (double)vol[c * V + i];
+            s1 += x; s2 += x * x; cnt += 1.0;
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off);
+        s2 += __shfl_down(s2, off);
+        cnt += __shfl_down(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(sums + c * 3 + 0, s1);
+        atomicAdd(sums + c * 3 + 1, s2);
+        atomicAdd(sums + c * 3 + 2, cnt);
+    }
+}
+
+__global__ void masked_zscore_kernel(float *vol, const uint8_t *mask, int64_t V, const double *sums) {
+    const int c = blockIdx.y;
+    const double cnt = sums[c * 3 + 2];
+    const double mean = cnt > 0 ? sums[c * 3 + 0] / cnt : 0.0;
+    double var = cnt > 0 ? sums[c * 3 + 1] / cnt - mean * mean : 0.0;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean;
+    const float denom = (float)sqrt(var) + 1e-8f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x)
+        vol[c * V + i] = mask[i] ? (vol[c * V + i] - meanf) / denom : 0.f;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" int mi355_regions_to_labels(const float *probs_dev, int C, int Z, int Y, int X, const int32_t *order,
+                                       const int32_t bbox_lo[3], const int32_t full[3], uint8_t *labels_dev,
+                                       void *stream) {
+    MI355_REQUIRE(C >= 1 && C <= 8, "regions_to_labels: %d channels", C);
+    MI355_REQUIRE(bbox_lo[0] >= 0 && bbox_lo[1] >= 0 && bbox_lo[2] >= 0 && bbox_lo[0] + Z <= full[0] &&
+                      bbox_lo[1] + Y <= full[1] && bbox_lo[2] + X <= full[2],
+                  "regions_to_labels: crop box does not fit the full volume");
+    hipStream_t s = (hipStream_t)stream;
+    OrderList ol;
+    for (int i = 0; i < 8; ++i) ol.v[i] = i < C ? order[i] : 0;
+    MI355_HIP(hipMemsetAsync(labels_dev, 0, (size_t)full[0] * full[1] * full[2], s));
+    const int64_t ZYX = (int64_t)Z * Y * X;
+    int64_t blocks = (ZYX + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(regions_to_labels_kernel, dim3((unsigned)blocks), dim3(256), 0, s, probs_dev, C, Z, Y, X, ol,
+                       bbox_lo[0], bbox_lo[1], bbox_lo[2], full[1], full[2], labels_dev);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+extern "C" int mi355_label_ensemble(const uint8_t *a_dev, const uint8_t *b_dev, uint8_t *out_dev, int64_t n,
+                                    void *stream) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(label_ensemble_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a_dev,
+                       b_dev, out_dev, n);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+extern "C" int mi355_prob_mean(const float *a_dev, const float *b_dev, float *out_dev, int64_t n, void *stream) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(prob_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a_dev, b_dev,
+                       out_dev, n);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+extern "C" int mi355_zscore_masked(float *vol_dev, const uint8_t *mask_dev, int C, int64_t voxels, void *stream) {
+    MI355_REQUIRE(C >= 1 && C <= 64, "zscore: %d channels", C);
+    hipStream_t s = (hipStream_t)stream;
+    double *sums = nullptr;
+    MI355_HIP(hipMalloc(&sums, (size_t)C * 3 * sizeof(double)));
+    MI355_HIP(hipMemsetAsync(sums, 0, (size_t)C * 3 * sizeof(double), s));
+    int64_t blocks = (voxels + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(masked_sums_kernel, dim3((unsigned)blocks, C), dim3(256), 0, s, vol_dev, mask_dev, voxels, sums);
+    hipLaunchKernelGGL(masked_zscore_kernel, dim3((unsigned)blocks, C), dim3(256), 0, s, vol_dev, mask_dev, voxels, sums);
+    MI355_HIP(hipGetLastError());
+    MI355_HIP(hipStreamSynchronize(s));
+    MI355_HIP(hipFree(sums));
+    return MI355_OK;
+}

@@ -1,0 +1,95 @@
+// Host-side launchers of the gfx950 kernels (declarations).  All tensors are NDHWC.
+#pragma once
+#include <vector>
+
+#include "common.h"
+
+namespace mi355 {
+
+enum { ACT_NONE = 0, ACT_LRELU = 1 };
+
+// ---------------------------------------------------------------- conv 3x3x3 (implicit GEMM)
+// Weights packed for the MFMA B operand; see pack_conv_weights_f32 in conv3d.hip.
+struct ConvWeights {
+    int cin = 0, cin_pad = 0, cout = 0, stride = 1;
+    int cc = 0;               // channel chunk staged in LDS per pass
+    int nf = 1;               // 32-wide cout fragments per workgroup
+    float *wp_dev = nullptr;  // packed weights (device)
+    float *bias_dev = nullptr;
+    float *w_plain_dev = nullptr;  // [cout][cin][27] PyTorch order (direct kernel / tests)
+    size_t wp_bytes = 0;
+};
+
+int conv_weights_upload(const float *w_host, const float *bias_host, int cin, int cin_pad, int cout,
+                        int stride, bool keep_plain, ConvWeights *out);
+void conv_weights_free(ConvWeights *w);
+
+struct ConvCall {
+    const float *in0 = nullptr;  // [N,Di,Hi,Wi,C0]
+    const float *in1 = nullptr;  // [N,Di,Hi,Wi,C1] second half of a virtual concat, or null
+    int C0 = 0, C1 = 0;
+    int N = 0, Di = 0, Hi = 0, Wi = 0;
+    float *out = nullptr;     // [N,Do,Ho,Wo,Cout]
+    double *stats = nullptr;  // [N][Cout][2] (sum, sum of squares) accumulated when non-null
+    int act = ACT_NONE;
+    float slope = 0.01f;
+};
+int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s);
+int conv3d_direct_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s);
+
+// ---------------------------------------------------------------- transposed conv k=2 s=2
+struct TConvWeights {
+    int cin = 0, cout = 0;
+    float *wp_dev = nullptr;
+};
+int tconv_weights_upload(const float *w_host, int cin, int cout, TConvWeights *out);
+void tconv_weights_free(TConvWeights *w);
+// in [N,D,H,W,Cin] -> out [N,2D,2H,2W,Cout]
+int tconv2_mfma_f32(const TConvWeights &w, const float *in, int N, int D, int H, int W, float *out,
+                    hipStream_t s);
+
+// ---------------------------------------------------------------- normalisation
+// stats [N][C][2] doubles -> scale/shift [N][C] so that y = x*scale + shift.
+int norm_finalize(const double *stats, int N, int C, int64_t count, int kind, int groups, float eps,
+                  const float *gamma, const float *beta, float *scale, float *shift, hipStream_t s);
+// in place: x = act(x*scale[n][c] + shift[n][c]) over [N][V][C]
+int norm_apply(float *x, int N, int64_t V, int C, const float *scale, const float *shift, int act,
+               float slope, hipStream_t s);
+
+// ---------------------------------------------------------------- tiles / head / aggregate
+struct TileDesc {  // one forward sample = one (tile, mirror)
+    int z0, y0, x0;  // origin in the padded volume
+    int mirror;      // bit0 flip z, bit1 flip y, bit2 flip x
+};
+// vol [C][Z][Y][X] (unpadded; pad offsets give where it sits in the padded volume)
+// -> x [n_samples][P0][P1][P2][Cpad] (channels >= C are zero)
+int extract_tiles(const float *vol, int C, int Z, int Y, int X, int padz, int pady, int padx,
+                  const TileDesc *tiles_host, int n_samples, int P0, int P1, int P2, int Cpad, float *x,
+                  hipStream_t s);
+// NCDHW -> NDHWC(Cpad) for the plain forward API
+int nchw_to_ndhwc(const float *x, int N, int C, int64_t V, int Cpad, float *y, hipStream_t s);
+
+struct HeadWeights {
+    int cin = 0, ncls = 0;
+    float *w_dev = nullptr;  // [ncls][cin]
+    float *b_dev = nullptr;  // [ncls]
+};
+int head_weights_upload(const float *w_host, const float *b_host, int cin, int ncls, HeadWeights *out);
+void head_weights_free(HeadWeights *w);
+// feat [N][V][C] -> logits [N][ncls][V]
+int head_logits(const HeadWeights &w, const float *feat, int N, int64_t V, float *logits, hipStream_t s);
+// One tile: result = sum_m (1/n_mirrors) * flip_back(nonlin(head(feat[first_sample+m])));
+// agg[c][tile] += result * gauss ; cnt[tile] += gauss (cnt may be null).
+int head_aggregate(const HeadWeights &w, const float *feat, int first_sample, const int *mirrors_host,
+                   int n_mirrors, int P0, int P1, int P2, int nonlin, const float *gauss, float *agg,
+                   float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, hipStream_t s);
+// probs[c][z][y][x] (+)= agg[c][z+pz][y+py][x+px] / cnt[...]; then optional scale (fold mean)
+int finish_probs(const float *agg, const float *cnt, int C, int Z, int Y, int X, int Zp, int Yp, int Xp,
+                 int pz, int py, int px, float *probs, int accumulate, hipStream_t s);
+int scale_inplace(float *x, int64_t n, float divisor, hipStream_t s);
+// cnt[tile] += gauss (or 1): the normaliser of a tile this rank does not evaluate itself
+int cnt_add_tile(const float *gauss, int P0, int P1, int P2, float *cnt, int Yp, int Xp, int z0, int y0, int x0,
+                 hipStream_t s);
+// in place: x = act(x*scale + shift), scale/shift [C] shared by every sample (un-folded BN)
+
+}  // namespace mi355

@@ -1,0 +1,122 @@
+// ConvTranspose3d(k=2, s=2, bias=False), NDHWC fp32, on the f32 matrix cores.
+//
+// Replaces the `tu[u]` modules of the reference decoder
+// (model_architecture/generic_UNet.py:363-364, applied at :435).  With kernel == stride the
+// op is 8 independent 1x1x1 GEMMs, one per output parity (a,b,c):
+//     out[n, 2z+a, 2y+b, 2x+c, co] = sum_ci in[n,z,y,x,ci] * W[ci, co, a, b, c]
+// M = input voxels (flattened N*D*H*W), K = Cin, N = Cout per parity.  A fragments are read
+// straight from global (16 B per lane: 4 channels of one voxel; lanes 0-31 / 32-63 take the two
+// halves of an 8-channel group, same K pairing as conv3d.hip); B fragments come from a
+// host-permuted pack.  1.6 % of the network's flops, so no LDS staging.
+#include "kernels.h"
+
+#include <vector>
+
+namespace mi355 {
+
+template <int MF>
+__global__ __launch_bounds__(256) void tconv2_f32_mfma_kernel(const float *__restrict__ in,
+                                                             const float *__restrict__ wp, float *out,
+                                                             int M, int Cin, int Cout, int D, int H, int W,
+                                                             FastDiv divW, FastDiv divH, FastDiv divD) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nblk = Cout >> 5;
+    const int pos = (int)blockIdx.y / nblk, nb = (int)blockIdx.y - pos * nblk;
+    const int G = Cin >> 3;
+    const int m0 = ((int)blockIdx.x * 4 + wave) * (MF * 32);
+
+    const float *arow[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        int v = m0 + mf * 32 + l31;
+        if (v >= M) v = M - 1;  // clamp: rows past the end are computed and discarded
+        arow[mf] = in + (size_t)v * Cin + half * 4;
+    }
+    const float *wrow = wp + ((size_t)(pos * nblk + nb) * G) * 256 + lane * 4;
+
+    f32x16 acc[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[mf][r] = 0.f;
+
+#pragma unroll 2
+    for (int g = 0; g < G; ++g) {
+        f32x4 a[MF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+            a[mf] = *(const f32x4 *)(arow[mf] + g * 8);
+        const f32x4 b = *(const f32x4 *)(wrow + (size_t)g * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+                acc[mf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mf][j], b[j], acc[mf], 0, 0, 0);
+    }
+
+    const int pa = pos >> 2, pb = (pos >> 1) & 1, pc = pos & 1;
+    const int co = nb * 32 + l31;
+    const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int v = m0 + mf * 32 + row;
+            if (v < M) {
+                const uint32_t q1 = fdiv((uint32_t)v, divW);
+                const int x = v - (int)q1 * W;
+                const uint32_t q2 = fdiv(q1, divH);
+                const int y = (int)q1 - (int)q2 * H;
+                const uint32_t n = fdiv(q2, divD);
+                const int z = (int)q2 - (int)n * D;
+                out[((((size_t)n * Do + 2 * z + pa) * Ho + 2 * y + pb) * Wo + 2 * x + pc) * Cout + co] =
+                    acc[mf][r];
+            }
+        }
+    }
+}
+
+// pack: [pos = a*4+b*2+c][cout block][g][lane][j]; cout = nb*32 + (lane&31), cin = g*8 + (lane>>5)*4 + j
+int tconv_weights_upload(const float *w_host, int cin, int cout, TConvWeights *out) {
+    MI355_REQUIRE(cin % 8 == 0 && cout % 32 == 0, "tconv %d->%d: need cin %% 8 == 0 and cout %% 32 == 0", cin, cout);
+    const int G = cin / 8, nblk = cout / 32;
+    std::vector<float> packed((size_t)8 * nblk * G * 256);
+    size_t o = 0;
+    for (int pos = 0; pos < 8; ++pos)
+        for (int nb = 0; nb < nblk; ++nb)
+            for (int g = 0; g < G; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j, ++o) {
+                        const int co = nb * 32 + (lane & 31);
+                        const int ci = g * 8 + (lane >> 5) * 4 + j;
+                        packed[o] = w_host[((size_t)ci * cout + co) * 8 + pos];
+                    }
+    TConvWeights tw;
+    tw.cin = cin; tw.cout = cout;
+    MI355_HIP(hipMalloc(&tw.wp_dev, packed.size() * sizeof(float)));
+    MI355_HIP(hipMemcpy(tw.wp_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = tw;
+    return MI355_OK;
+}
+
+void tconv_weights_free(TConvWeights *w) {
+    if (w->wp_dev) (void)hipFree(w->wp_dev);
+    *w = TConvWeights();
+}
+
+int tconv2_mfma_f32(const TConvWeights &w, const float *in, int N, int D, int H, int W, float *out,
+                    hipStream_t s) {
+    const long M = (long)N * D * H * W;
+    MI355_REQUIRE(M > 0 && M < (1l << 30), "tconv: %ld voxels out of range", M);
+    constexpr int MF = 2;
+    dim3 grid((unsigned)((M + 4 * MF * 32 - 1) / (4 * MF * 32)), 8 * (w.cout / 32));
+    hipLaunchKernelGGL(tconv2_f32_mfma_kernel<MF>, grid, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cin,
+                       w.cout, D, H, W, make_fastdiv(W), make_fastdiv(H), make_fastdiv(D));
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+}  // namespace mi355

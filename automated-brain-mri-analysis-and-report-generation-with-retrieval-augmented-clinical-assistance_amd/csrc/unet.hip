@@ -1,0 +1,604 @@
+// Network object, activation arena, forward pass and the sliding-window predictor (host side),
+// plus the extern "C" entry points declared in include/mi355_nnunet.h.
+//
+// Reference behaviour restated here:
+//   * Generic_UNet.forward                 model_architecture/generic_UNet.py:423-446
+//   * eval-mode BatchNorm folded into the preceding conv (ConvDropoutNormNonlin :68-72)
+//   * nnU-Net v1 SegmentationNetwork._internal_predict_3D_3Dconv_tiled / _compute_steps_for_
+//     sliding_window / _get_gaussian / _internal_maybe_mirror_and_pred_3D (un-vendored upstream;
+//     SURVEY.md 8a rows T1-T5) as driven by run_brats2021_inference_singlethread.py:97-128.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace mi355 {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+struct ConvLayer {
+    ConvWeights w;
+    float *gamma_dev = nullptr, *beta_dev = nullptr;  // Instance/GroupNorm affine, or BN scale/shift (nonlin_first)
+    bool runtime_norm = false;                        // statistics needed at run time (IN / GN)
+    bool post_affine = false;                         // BN that could not be folded (nonlin_first)
+    int cin = 0, cout = 0, stride = 1;
+};
+
+}  // namespace mi355
+
+using namespace mi355;
+
+struct mi355_unet {
+    int in_channels = 0, cin_pad = 0, num_classes = 0, num_pool = 0;
+    int norm = 0, num_groups = 0, nonlin_first = 0, dtype = 0;
+    float eps = 1e-5f, slope = 0.01f;
+    std::vector<std::vector<ConvLayer>> enc;  // num_pool + 1 stages
+    std::vector<std::vector<ConvLayer>> dec;  // num_pool stages
+    std::vector<TConvWeights> tu;
+    HeadWeights head;
+    // activation arena
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    // gaussian importance map cache
+    float *gauss_dev = nullptr;
+    int gauss_p[3] = {0, 0, 0};
+    int max_channels = 0;
+};
+
+namespace mi355 {
+
+static int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (%s); this library has no CPU fallback", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        return MI355_ERR_NO_DEVICE;
+    }
+    return MI355_OK;
+}
+
+static int upload(const float *host, size_t n, float **dev) {
+    MI355_HIP(hipMalloc(dev, n * sizeof(float)));
+    MI355_HIP(hipMemcpy(*dev, host, n * sizeof(float), hipMemcpyHostToDevice));
+    return MI355_OK;
+}
+
+static int build_conv(const mi355_unet &net, const mi355_conv_desc &d, int cin_phys, ConvLayer *out) {
+    MI355_REQUIRE(d.weight != nullptr, "conv %d->%d: null weight", d.cin, d.cout);
+    MI355_REQUIRE(d.cin > 0 && d.cout > 0 && cin_phys >= d.cin, "conv: bad channel counts %d->%d (phys %d)", d.cin, d.cout, cin_phys);
+    ConvLayer L;
+    L.cin = d.cin; L.cout = d.cout; L.stride = d.stride;
+    const size_t wn = (size_t)d.cout * d.cin * 27;
+    std::vector<float> w(d.weight, d.weight + wn);
+    std::vector<float> b(d.cout, 0.f);
+    if (d.bias) b.assign(d.bias, d.bias + d.cout);
+    if (net.norm == MI355_NORM_BATCH) {
+        MI355_REQUIRE(d.running_mean && d.running_var, "BatchNorm conv %d->%d: running stats missing", d.cin, d.cout);
+        std::vector<float> sc(d.cout), sh(d.cout);
+        for (int co = 0; co < d.cout; ++co) {
+            const double g = d.gamma ? d.gamma[co] : 1.0, be = d.beta ? d.beta[co] : 0.0;
+            const double s = g / std::sqrt((double)d.running_var[co] + (double)net.eps);
+            sc[co] = (float)s;
+            sh[co] = (float)(be - (double)d.running_mean[co] * s);
+        }
+        if (!net.nonlin_first) {
+            // y = lrelu(BN(conv(x)+b)) = lrelu(conv'(x) + b')  with w' = w*s, b' = b*s + shift
+            for (int co = 0; co < d.cout; ++co) {
+                const double s = sc[co];
+                for (size_t k = 0; k < (size_t)d.cin * 27; ++k)
+                    w[(size_t)co * d.cin * 27 + k] = (float)((double)w[(size_t)co * d.cin * 27 + k] * s);
+                b[co] = (float)((double)b[co] * s + (double)sh[co]);
+            }
+        } else {
+            L.post_affine = true;
+            MI355_TRY(upload(sc.data(), d.cout, &L.gamma_dev));
+            MI355_TRY(upload(sh.data(), d.cout, &L.beta_dev));
+        }
+    } else if (net.norm == MI355_NORM_INSTANCE || net.norm == MI355_NORM_GROUP) {
+        L.runtime_norm = true;
+        std::vector<float> g(d.cout, 1.f), be(d.cout, 0.f);
+        if (d.gamma) g.assign(d.gamma, d.gamma + d.cout);
+        if (d.beta) be.assign(d.beta, d.beta + d.cout);
+        MI355_TRY(upload(g.data(), d.cout, &L.gamma_dev));
+        MI355_TRY(upload(be.data(), d.cout, &L.beta_dev));
+    }
+    MI355_TRY(conv_weights_upload(w.data(), b.data(), d.cin, cin_phys, d.cout, d.stride, false, &L.w));
+    *out = L;
+    return MI355_OK;
+}
+
+static void free_conv(ConvLayer *L) {
+    conv_weights_free(&L->w);
+    if (L->gamma_dev) (void)hipFree(L->gamma_dev);
+    if (L->beta_dev) (void)hipFree(L->beta_dev);
+}
+
+static void destroy(mi355_unet *net) {
+    if (!net) return;
+    for (auto &st : net->enc) for (auto &L : st) free_conv(&L);
+    for (auto &st : net->dec) for (auto &L : st) free_conv(&L);
+    for (auto &t : net->tu) tconv_weights_free(&t);
+    head_weights_free(&net->head);
+    if (net->arena) (void)hipFree(net->arena);
+    if (net->gauss_dev) (void)hipFree(net->gauss_dev);
+    delete net;
+}
+
+// ---- arena layout for one (N, D, H, W): per level four activation buffers + norm scratch
+struct Plan {
+    std::vector<int64_t> vox;          // voxels per sample at each level
+    std::vector<int> maxc;             // widest tensor at each level
+    std::vector<size_t> off[4];        // byte offsets of buffers A, B, U, T per level
+    size_t stats_off = 0, scale_off = 0, shift_off = 0, x0_off = 0, total = 0;
+    size_t stats_bytes = 0;
+};
+
+static int make_plan(const mi355_unet &net, int N, int D, int H, int W, Plan *pl) {
+    const int np = net.num_pool;
+    MI355_REQUIRE(D % (1 << np) == 0 && H % (1 << np) == 0 && W % (1 << np) == 0,
+                  "patch %dx%dx%d must be divisible by %d (generic_UNet.py:256)", D, H, W, 1 << np);
+    pl->vox.resize(np + 1);
+    pl->maxc.assign(np + 1, 0);
+    for (int l = 0; l <= np; ++l) {
+        pl->vox[l] = (int64_t)(D >> l) * (H >> l) * (W >> l);
+        for (auto &L : net.enc[l]) pl->maxc[l] = std::max(pl->maxc[l], L.cout);
+    }
+    for (int u = 0; u < np; ++u) {
+        const int l = np - 1 - u;
+        pl->maxc[l] = std::max(pl->maxc[l], net.tu[u].cout);
+        for (auto &L : net.dec[u]) pl->maxc[l] = std::max(pl->maxc[l], L.cout);
+    }
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~size_t(255); return r; };
+    pl->x0_off = take((size_t)N * pl->vox[0] * net.cin_pad * sizeof(float));
+    for (int k = 0; k < 4; ++k) pl->off[k].resize(np + 1);
+    for (int l = 0; l <= np; ++l)
+        for (int k = 0; k < 4; ++k)
+            pl->off[k][l] = take((size_t)N * pl->vox[l] * pl->maxc[l] * sizeof(float));
+    pl->stats_bytes = (size_t)N * net.max_channels * 2 * sizeof(double);
+    pl->stats_off = take(pl->stats_bytes);
+    pl->scale_off = take((size_t)N * net.max_channels * sizeof(float));
+    pl->shift_off = take((size_t)N * net.max_channels * sizeof(float));
+    pl->total = o;
+    return MI355_OK;
+}
+
+static int ensure_arena(mi355_unet *net, size_t bytes) {
+    if (net->arena_bytes >= bytes) return MI355_OK;
+    if (net->arena) {
+        MI355_HIP(hipDeviceSynchronize());
+        MI355_HIP(hipFree(net->arena));
+        net->arena = nullptr; net->arena_bytes = 0;
+    }
+    MI355_HIP(hipMalloc(&net->arena, bytes));
+    net->arena_bytes = bytes;
+    return MI355_OK;
+}
+
+// One ConvDropoutNormNonlin / ConvDropoutNonlinNorm block.
+static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const float *in0, int C0,
+                     const float *in1, int C1, int N, int Di, int Hi, int Wi, float *out, hipStream_t s) {
+    ConvCall c;
+    c.in0 = in0; c.in1 = in1; c.C0 = C0; c.C1 = C1;
+    c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi;
+    c.out = out; c.slope = net->slope;
+    double *stats = (double *)(net->arena + pl.stats_off);
+    float *scale = (float *)(net->arena + pl.scale_off), *shift = (float *)(net->arena + pl.shift_off);
+    if (L.runtime_norm) {
+        c.act = net->nonlin_first ? ACT_LRELU : ACT_NONE;
+        c.stats = stats;
+        MI355_HIP(hipMemsetAsync(stats, 0, (size_t)N * L.cout * 2 * sizeof(double), s));
+    } else {
+        c.act = ACT_LRELU;
+    }
+    if (L.w.wp_dev) MI355_TRY(conv3d_mfma_f32(L.w, c, s));
+    else MI355_TRY(conv3d_direct_f32(L.w, c, s));
+    const int st = L.stride;
+    const int64_t Vo = (int64_t)((Di - 1) / st + 1) * ((Hi - 1) / st + 1) * ((Wi - 1) / st + 1);
+    if (L.runtime_norm) {
+        MI355_TRY(norm_finalize(stats, N, L.cout, Vo, net->norm, net->num_groups, net->eps, L.gamma_dev, L.beta_dev,
+                                scale, shift, s));
+        MI355_TRY(norm_apply(out, N, Vo, L.cout, scale, shift, net->nonlin_first ? ACT_NONE : ACT_LRELU, net->slope, s));
+    } else if (L.post_affine) {
+        // BN after the nonlinearity: per-channel affine, identical for every sample
+        for (int n = 0; n < N; ++n)
+            MI355_TRY(norm_apply(out + (size_t)n * Vo * L.cout, 1, Vo, L.cout, L.gamma_dev, L.beta_dev, ACT_NONE,
+                                 net->slope, s));
+    }
+    return MI355_OK;
+}
+
+// x0: [N,D,H,W,cin_pad] already in the arena at pl.x0_off.  Returns the last decoder feature map.
+static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H, int W, const float **feat,
+                            int *feat_c, hipStream_t s) {
+    const int np = net->num_pool;
+    auto buf = [&](int k, int l) { return (float *)(net->arena + pl.off[k][l]); };
+    const float *cur = (const float *)(net->arena + pl.x0_off);
+    int curC = net->cin_pad;
+    std::vector<const float *> skip(np);
+    std::vector<int> skipC(np);
+    // encoder + bottleneck
+    for (int l = 0; l <= np; ++l) {
+        int Di = D >> l, Hi = H >> l, Wi = W >> l;
+        for (size_t i = 0; i < net->enc[l].size(); ++i) {
+            const ConvLayer &L = net->enc[l][i];
+            int inD = Di, inH = Hi, inW = Wi;
+            if (L.stride == 2) { inD = Di * 2; inH = Hi * 2; inW = Wi * 2; }
+            float *out = buf((int)(i & 1), l);
+            MI355_TRY(run_block(net, pl, L, cur, curC, nullptr, 0, N, inD, inH, inW, out, s));
+            cur = out; curC = L.cout;
+        }
+        if (l < np) { skip[l] = cur; skipC[l] = curC; }
+    }
+    // decoder
+    for (int u = 0; u < np; ++u) {
+        const int l = np - 1 - u;
+        const int Dl = D >> l, Hl = H >> l, Wl = W >> l;
+        float *up = buf(2, l);
+        MI355_REQUIRE(net->tu[u].cin == curC, "tu.%d expects %d channels, got %d", u, net->tu[u].cin, curC);
+        MI355_TRY(tconv2_mfma_f32(net->tu[u], cur, N, Dl / 2, Hl / 2, Wl / 2, up, s));
+        // concat order (upsampled, skip): generic_UNet.py:438 - never materialised
+        const float *in0 = up, *in1 = skip[l];
+        int C0 = net->tu[u].cout, C1 = skipC[l];
+        // outputs alternate between T and whichever of A/B is not the skip
+        float *freeAB = (skip[l] == buf(0, l)) ? buf(1, l) : buf(0, l);
+        for (size_t i = 0; i < net->dec[u].size(); ++i) {
+            const ConvLayer &L = net->dec[u][i];
+            float *out = (i & 1) ? freeAB : buf(3, l);
+            MI355_TRY(run_block(net, pl, L, in0, C0, in1, C1, N, Dl, Hl, Wl, out, s));
+            in0 = out; C0 = L.cout; in1 = nullptr; C1 = 0;
+        }
+        cur = in0; curC = C0;
+    }
+    *feat = cur; *feat_c = curC;
+    return MI355_OK;
+}
+
+// ---- sliding-window helpers (nnU-Net v1)
+static std::vector<int> compute_steps(int patch, int image, double step_size) {
+    // target = patch*step ; n = ceil((image-patch)/target)+1 ; actual = (image-patch)/(n-1)
+    const double target = patch * step_size;
+    const int n = (int)std::ceil((image - patch) / target) + 1;
+    const int max_step = image - patch;
+    const double actual = n > 1 ? (double)max_step / (n - 1) : 99999999999.0;
+    std::vector<int> steps(n);
+    for (int i = 0; i < n; ++i) steps[i] = (int)std::nearbyint(actual * i);  // np.round: half to even
+    return steps;
+}
+
+// scipy.ndimage.gaussian_filter(delta at patch//2, sigma = patch*sigma_scale, mode='constant') is
+// separable: the filtered delta is the outer product of the three normalised 1-D kernels
+// (truncate=4.0 -> radius int(4*sigma+0.5)); then /max, fp32, zeros -> smallest non-zero.
+static void gaussian_map(const int p[3], double sigma_scale, std::vector<float> &out) {
+    std::vector<double> ax[3];
+    for (int a = 0; a < 3; ++a) {
+        const double sigma = p[a] * sigma_scale;
+        const int radius = (int)(4.0 * sigma + 0.5);
+        double sum = 0.0;
+        std::vector<double> k(2 * radius + 1);
+        for (int i = -radius; i <= radius; ++i) { k[i + radius] = std::exp(-0.5 / (sigma * sigma) * (double)i * i); sum += k[i + radius]; }
+        ax[a].assign(p[a], 0.0);
+        const int c = p[a] / 2;
+        for (int i = 0; i < p[a]; ++i) {
+            const int o = i - c;
+            if (o >= -radius && o <= radius) ax[a][i] = k[o + radius] / sum;
+        }
+    }
+    const size_t n = (size_t)p[0] * p[1] * p[2];
+    std::vector<double> g(n);
+    double mx = 0.0;
+    for (int z = 0; z < p[0]; ++z)
+        for (int y = 0; y < p[1]; ++y)
+            for (int x = 0; x < p[2]; ++x) {
+                const double v = (ax[0][z] * ax[1][y]) * ax[2][x];
+                g[((size_t)z * p[1] + y) * p[2] + x] = v;
+                if (v > mx) mx = v;
+            }
+    out.resize(n);
+    float mn = INFINITY;
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = (float)(g[i] / mx * 1.0);
+        if (out[i] != 0.f && out[i] < mn) mn = out[i];
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (out[i] == 0.f) out[i] = mn;
+}
+
+static int ensure_gaussian(mi355_unet *net, const int p[3]) {
+    if (net->gauss_dev && net->gauss_p[0] == p[0] && net->gauss_p[1] == p[1] && net->gauss_p[2] == p[2])
+        return MI355_OK;
+    if (net->gauss_dev) { MI355_HIP(hipDeviceSynchronize()); MI355_HIP(hipFree(net->gauss_dev)); net->gauss_dev = nullptr; }
+    std::vector<float> g;
+    gaussian_map(p, 1.0 / 8.0, g);
+    MI355_TRY(upload(g.data(), g.size(), &net->gauss_dev));
+    net->gauss_p[0] = p[0]; net->gauss_p[1] = p[1]; net->gauss_p[2] = p[2];
+    return MI355_OK;
+}
+
+struct SwGeom {
+    int P[3], Zp[3], pad_lo[3];
+    std::vector<TileDesc> tiles;   // origin of every tile, loop order axis0 outer .. axis2 inner
+    std::vector<int> mirrors;      // TileDesc-style masks in nnU-Net's evaluation order
+};
+
+static int make_geom(const mi355_sw_opts &o, int Z, int Y, int X, SwGeom *g) {
+    const int dims[3] = {Z, Y, X};
+    std::vector<int> steps[3];
+    for (int a = 0; a < 3; ++a) {
+        g->P[a] = o.patch[a];
+        MI355_REQUIRE(g->P[a] > 0 && dims[a] > 0, "bad patch / volume size");
+        g->Zp[a] = std::max(dims[a], g->P[a]);       // pad_nd_image(..., "constant", 0)
+        g->pad_lo[a] = (g->Zp[a] - dims[a]) / 2;     // pad_below = difference // 2
+        steps[a] = compute_steps(g->P[a], g->Zp[a], o.step_size);
+    }
+    MI355_REQUIRE(o.step_size > 0.f && o.step_size <= 1.f, "step_size must be in (0, 1]");
+    g->tiles.clear();
+    for (int z : steps[0]) for (int y : steps[1]) for (int x : steps[2]) g->tiles.push_back(TileDesc{z, y, x, 0});
+    // _internal_maybe_mirror_and_pred_3D: m = 0..7; bit0 of m flips the LAST axis (x), bit1 y, bit2 z
+    g->mirrors.clear();
+    for (int m = 0; m < 8; ++m) {
+        const bool fx = m & 1, fy = m & 2, fz = m & 4;
+        if ((fx && !(o.mirror_axes & 4)) || (fy && !(o.mirror_axes & 2)) || (fz && !(o.mirror_axes & 1))) continue;
+        g->mirrors.push_back((fz ? 1 : 0) | (fy ? 2 : 0) | (fx ? 4 : 0));
+    }
+    return MI355_OK;
+}
+
+// Evaluates the tiles with (index % world) == rank of one net; adds into agg (and cnt if non-null,
+// for ALL tiles so that every rank holds the full normaliser).
+static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X, const mi355_sw_opts &o,
+                         const SwGeom &g, int rank, int world, float *agg, float *cnt, hipStream_t s) {
+    const int nm = (int)g.mirrors.size();
+    const bool use_gauss = o.use_gaussian && g.tiles.size() > 1;
+    if (use_gauss) MI355_TRY(ensure_gaussian(net, g.P));
+    std::vector<int> mine;
+    for (size_t t = 0; t < g.tiles.size(); ++t) if ((int)(t % world) == rank) mine.push_back((int)t);
+    int bt = o.batch_tiles > 0 ? o.batch_tiles : std::max(1, 16 / nm);
+    if (bt * nm > 64) bt = std::max(1, 64 / nm);
+    MI355_REQUIRE(nm <= 64, "too many mirrors");
+    Plan pl;
+    MI355_TRY(make_plan(*net, bt * nm, g.P[0], g.P[1], g.P[2], &pl));
+    MI355_TRY(ensure_arena(net, pl.total));
+    for (size_t b0 = 0; b0 < mine.size(); b0 += bt) {
+        const int nb = (int)std::min<size_t>(bt, mine.size() - b0);
+        std::vector<TileDesc> samples;
+        for (int i = 0; i < nb; ++i)
+            for (int m = 0; m < nm; ++m) {
+                TileDesc td = g.tiles[mine[b0 + i]];
+                td.mirror = g.mirrors[m];
+                samples.push_back(td);
+            }
+        MI355_TRY(extract_tiles(vol, net->in_channels, Z, Y, X, g.pad_lo[0], g.pad_lo[1], g.pad_lo[2], samples.data(),
+                                (int)samples.size(), g.P[0], g.P[1], g.P[2], net->cin_pad,
+                                (float *)(net->arena + pl.x0_off), s));
+        const float *feat; int fc;
+        MI355_TRY(forward_features(net, pl, (int)samples.size(), g.P[0], g.P[1], g.P[2], &feat, &fc, s));
+        MI355_REQUIRE(fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
+        for (int i = 0; i < nb; ++i) {
+            const TileDesc &td = g.tiles[mine[b0 + i]];
+            MI355_TRY(head_aggregate(net->head, feat, i * nm, g.mirrors.data(), nm, g.P[0], g.P[1], g.P[2], o.nonlin,
+                                     use_gauss ? net->gauss_dev : nullptr, agg, (cnt && world == 1) ? cnt : nullptr,
+                                     g.Zp[0], g.Zp[1], g.Zp[2], td.z0, td.y0, td.x0, s));
+        }
+    }
+    return MI355_OK;
+}
+
+}  // namespace mi355
+
+// =============================================================================== C ABI
+extern "C" const char *mi355_last_error(void) { return g_last_error.c_str(); }
+extern "C" int mi355_version(void) { return 100; }
+extern "C" int mi355_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int mi355_unet_create(const mi355_unet_desc *d, mi355_unet_t *out) {
+    MI355_REQUIRE(d && out, "null argument");
+    MI355_TRY(require_device());
+    MI355_REQUIRE(d->dtype == MI355_F32, "dtype %d: only MI355_F32 is built in this version", d->dtype);
+    MI355_REQUIRE(d->num_pool >= 1 && d->num_pool <= 7, "num_pool %d out of range", d->num_pool);
+    MI355_REQUIRE(d->in_channels >= 1 && d->in_channels <= 8, "in_channels %d unsupported (1..8)", d->in_channels);
+    MI355_REQUIRE(d->norm >= MI355_NORM_NONE && d->norm <= MI355_NORM_GROUP, "norm kind %d", d->norm);
+    mi355_unet *net = new mi355_unet();
+    net->in_channels = d->in_channels; net->cin_pad = 8; net->num_classes = d->num_classes;
+    net->num_pool = d->num_pool; net->norm = d->norm; net->num_groups = d->num_groups;
+    net->nonlin_first = d->nonlin_first; net->dtype = d->dtype; net->eps = d->eps; net->slope = d->lrelu_slope;
+    int rc = MI355_OK;
+    int ci = 0;
+    int prevC = net->cin_pad;
+    net->enc.resize(d->num_pool + 1);
+    net->dec.resize(d->num_pool);
+    net->tu.resize(d->num_pool);
+    std::vector<int> skipC(d->num_pool, 0);
+    auto fail = [&](int code) { destroy(net); return code; };
+    for (int l = 0; l <= d->num_pool && rc == MI355_OK; ++l) {
+        if (d->enc_convs[l] < 1) { set_error("encoder stage %d has no convs", l); return fail(MI355_ERR_INVALID); }
+        for (int i = 0; i < d->enc_convs[l]; ++i) {
+            if (ci >= d->n_convs) { set_error("conv list too short"); return fail(MI355_ERR_INVALID); }
+            const mi355_conv_desc &cd = d->convs[ci++];
+            const int want_stride = (l > 0 && i == 0) ? 2 : 1;
+            if (cd.stride != want_stride) { set_error("encoder conv %d.%d: stride %d, expected %d", l, i, cd.stride, want_stride); return fail(MI355_ERR_INVALID); }
+            const int logical_in = (l == 0 && i == 0) ? d->in_channels : prevC;
+            if (cd.cin != logical_in) { set_error("encoder conv %d.%d: cin %d, expected %d", l, i, cd.cin, logical_in); return fail(MI355_ERR_INVALID); }
+            ConvLayer L;
+            rc = build_conv(*net, cd, prevC, &L);
+            if (rc != MI355_OK) return fail(rc);
+            net->enc[l].push_back(L);
+            prevC = cd.cout;
+            net->max_channels = std::max(net->max_channels, cd.cout);
+        }
+        if (l < d->num_pool) skipC[l] = prevC;
+    }
+    for (int u = 0; u < d->num_pool; ++u) {
+        const int l = d->num_pool - 1 - u;
+        const mi355_tconv_desc &td = d->tconvs[u];
+        if (td.cin != prevC) { set_error("tu.%d: cin %d, expected %d", u, td.cin, prevC); return fail(MI355_ERR_INVALID); }
+        rc = tconv_weights_upload(td.weight, td.cin, td.cout, &net->tu[u]);
+        if (rc != MI355_OK) return fail(rc);
+        net->max_channels = std::max(net->max_channels, td.cout);
+        int inC = td.cout + skipC[l];
+        if (d->dec_convs[u] < 1) { set_error("decoder stage %d has no convs", u); return fail(MI355_ERR_INVALID); }
+        for (int i = 0; i < d->dec_convs[u]; ++i) {
+            if (ci >= d->n_convs) { set_error("conv list too short"); return fail(MI355_ERR_INVALID); }
+            const mi355_conv_desc &cd = d->convs[ci++];
+            if (cd.stride != 1 || cd.cin != inC) { set_error("decoder conv %d.%d: cin %d stride %d, expected %d / 1", u, i, cd.cin, cd.stride, inC); return fail(MI355_ERR_INVALID); }
+            ConvLayer L;
+            rc = build_conv(*net, cd, inC, &L);
+            if (rc != MI355_OK) return fail(rc);
+            net->dec[u].push_back(L);
+            inC = cd.cout;
+            net->max_channels = std::max(net->max_channels, cd.cout);
+        }
+        prevC = inC;
+    }
+    if (ci != d->n_convs) { set_error("%d convs given, topology uses %d", d->n_convs, ci); return fail(MI355_ERR_INVALID); }
+    if (d->head.cin != prevC || d->head.num_classes != d->num_classes) { set_error("head: cin %d classes %d, expected %d / %d", d->head.cin, d->head.num_classes, prevC, d->num_classes); return fail(MI355_ERR_INVALID); }
+    rc = head_weights_upload(d->head.weight, d->head.bias, d->head.cin, d->head.num_classes, &net->head);
+    if (rc != MI355_OK) return fail(rc);
+    *out = net;
+    return MI355_OK;
+}
+
+extern "C" int mi355_unet_destroy(mi355_unet_t net) {
+    destroy(net);
+    return MI355_OK;
+}
+
+extern "C" int64_t mi355_unet_flops(mi355_unet_t net, int d, int h, int w) {
+    if (!net) return -1;
+    const int np = net->num_pool;
+    int64_t total = 0;
+    auto vox = [&](int l) { return (int64_t)(d >> l) * (h >> l) * (w >> l); };
+    for (int l = 0; l <= np; ++l)
+        for (auto &L : net->enc[l]) total += 2 * vox(l) * L.cout * L.cin * 27;
+    for (int u = 0; u < np; ++u) {
+        const int l = np - 1 - u;
+        total += 2 * vox(l + 1) * net->tu[u].cin * net->tu[u].cout * 8;
+        for (auto &L : net->dec[u]) total += 2 * vox(l) * L.cout * L.cin * 27;
+    }
+    total += 2 * vox(0) * net->head.cin * net->head.ncls;
+    return total;
+}
+
+extern "C" int mi355_unet_forward(mi355_unet_t net, const float *x_dev, int n, int d, int h, int w, float *logits_dev,
+                                  void *stream) {
+    MI355_REQUIRE(net && x_dev && logits_dev && n > 0, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    Plan pl;
+    MI355_TRY(make_plan(*net, n, d, h, w, &pl));
+    MI355_TRY(ensure_arena(net, pl.total));
+    const int64_t V = (int64_t)d * h * w;
+    MI355_TRY(nchw_to_ndhwc(x_dev, n, net->in_channels, V, net->cin_pad, (float *)(net->arena + pl.x0_off), s));
+    const float *feat; int fc;
+    MI355_TRY(forward_features(net, pl, n, d, h, w, &feat, &fc, s));
+    MI355_REQUIRE(fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
+    MI355_TRY(head_logits(net->head, feat, n, V, logits_dev, s));
+    return MI355_OK;
+}
+
+extern "C" int mi355_compute_steps(int patch, int image, float step_size, int32_t *steps, int max_steps) {
+    MI355_REQUIRE(patch > 0 && image >= patch && step_size > 0.f && step_size <= 1.f, "compute_steps: bad arguments");
+    std::vector<int> st = compute_steps(patch, image, step_size);
+    MI355_REQUIRE((int)st.size() <= max_steps, "compute_steps: %zu steps > buffer %d", st.size(), max_steps);
+    for (size_t i = 0; i < st.size(); ++i) steps[i] = st[i];
+    return (int)st.size();
+}
+
+extern "C" int mi355_sw_partial(mi355_unet_t net, const float *vol_dev, int Z, int Y, int X, const mi355_sw_opts *opts,
+                                int rank, int world, float *agg_dev, float *cnt_dev, void *stream) {
+    MI355_REQUIRE(net && vol_dev && opts && agg_dev && world >= 1 && rank >= 0 && rank < world, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    SwGeom g;
+    MI355_TRY(make_geom(*opts, Z, Y, X, &g));
+    const size_t ZYXp = (size_t)g.Zp[0] * g.Zp[1] * g.Zp[2];
+    MI355_HIP(hipMemsetAsync(agg_dev, 0, ZYXp * net->num_classes * sizeof(float), s));
+    if (cnt_dev) MI355_HIP(hipMemsetAsync(cnt_dev, 0, ZYXp * sizeof(float), s));
+    if (cnt_dev && world > 1) {
+        // full normaliser on every rank: cnt[tile] += gaussian for ALL tiles, in tile order
+        const bool use_gauss = opts->use_gaussian && g.tiles.size() > 1;
+        if (use_gauss) MI355_TRY(ensure_gaussian(net, g.P));
+        for (const TileDesc &td : g.tiles)
+            MI355_TRY(cnt_add_tile(use_gauss ? net->gauss_dev : nullptr, g.P[0], g.P[1], g.P[2], cnt_dev, g.Zp[1], g.Zp[2],
+                                   td.z0, td.y0, td.x0, s));
+    }
+    return sw_accumulate(net, vol_dev, Z, Y, X, *opts, g, rank, world, agg_dev, cnt_dev, s);
+}
+
+extern "C" int mi355_sw_finish(const float *agg_dev, const float *cnt_dev, int num_classes, int Z, int Y, int X,
+                               const int32_t patch[3], float *probs_dev, void *stream) {
+    const int Zp = std::max(Z, patch[0]), Yp = std::max(Y, patch[1]), Xp = std::max(X, patch[2]);
+    return finish_probs(agg_dev, cnt_dev, num_classes, Z, Y, X, Zp, Yp, Xp, (Zp - Z) / 2, (Yp - Y) / 2, (Xp - X) / 2,
+                        probs_dev, 0, (hipStream_t)stream);
+}
+
+extern "C" int mi355_sw_predict(const mi355_unet_t *nets, int n_nets, const float *vol_dev, int Z, int Y, int X,
+                                const mi355_sw_opts *opts, float *probs_dev, void *stream) {
+    MI355_REQUIRE(nets && n_nets >= 1 && vol_dev && opts && probs_dev, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    SwGeom g;
+    MI355_TRY(make_geom(*opts, Z, Y, X, &g));
+    const int C = nets[0]->num_classes;
+    const size_t ZYXp = (size_t)g.Zp[0] * g.Zp[1] * g.Zp[2];
+    float *agg = nullptr, *cnt = nullptr;
+    MI355_HIP(hipMalloc(&agg, ZYXp * C * sizeof(float)));
+    MI355_HIP(hipMalloc(&cnt, ZYXp * sizeof(float)));
+    int rc = MI355_OK;
+    for (int f = 0; f < n_nets && rc == MI355_OK; ++f) {
+        if (nets[f]->num_classes != C) { set_error("fold %d has %d classes, fold 0 has %d", f, nets[f]->num_classes, C); rc = MI355_ERR_INVALID; break; }
+        if (hipMemsetAsync(agg, 0, ZYXp * C * sizeof(float), s) != hipSuccess ||
+            hipMemsetAsync(cnt, 0, ZYXp * sizeof(float), s) != hipSuccess) { set_error("memset failed"); rc = MI355_ERR_HIP; break; }
+        rc = sw_accumulate(nets[f], vol_dev, Z, Y, X, *opts, g, 0, 1, agg, cnt, s);
+        if (rc == MI355_OK)
+            rc = finish_probs(agg, cnt, C, Z, Y, X, g.Zp[0], g.Zp[1], g.Zp[2], g.pad_lo[0], g.pad_lo[1], g.pad_lo[2],
+                              probs_dev, f > 0, s);
+    }
+    // fold mean: np.mean(list_of_fp32_arrays, axis=0) = fp32 running sum in list order, one divide
+    if (rc == MI355_OK && n_nets > 1) rc = scale_inplace(probs_dev, (int64_t)C * Z * Y * X, (float)n_nets, s);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(agg);
+    (void)hipFree(cnt);
+    if (rc == MI355_OK && e != hipSuccess) { set_error("stream sync failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
+    return rc;
+}
+
+extern "C" int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
+                                  const float *bias_host, int cout, int stride, int act, float slope, int impl, float *y_dev,
+                                  void *stream) {
+    MI355_TRY(require_device());
+    ConvWeights cw;
+    MI355_TRY(conv_weights_upload(weight_host, bias_host, cin, cin, cout, stride, impl == 1, &cw));
+    ConvCall c;
+    c.in0 = x_dev; c.C0 = cin; c.N = n; c.Di = d; c.Hi = h; c.Wi = w; c.out = y_dev; c.act = act; c.slope = slope;
+    int rc = (impl == 1) ? conv3d_direct_f32(cw, c, (hipStream_t)stream) : conv3d_mfma_f32(cw, c, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    conv_weights_free(&cw);
+    if (rc == MI355_OK && e != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
+    return rc;
+}
+
+extern "C" int mi355_tconv3d_ndhwc(const float *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
+                                   int cout, float *y_dev, void *stream) {
+    MI355_TRY(require_device());
+    TConvWeights tw;
+    MI355_TRY(tconv_weights_upload(weight_host, cin, cout, &tw));
+    int rc = tconv2_mfma_f32(tw, x_dev, n, d, h, w, y_dev, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    tconv_weights_free(&tw);
+    if (rc == MI355_OK && e != hipSuccess) { set_error("tconv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
+    return rc;
+}

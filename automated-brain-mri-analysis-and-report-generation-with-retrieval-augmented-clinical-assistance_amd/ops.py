@@ -1,0 +1,115 @@
+"""Thin torch-CUDA wrappers over the single-purpose C-ABI entry points.
+
+torch is used for device memory and streams only; every computation happens in the HIP
+library.  All functions raise ``Mi355Error`` if the library is missing or no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _stream(t):
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require_cuda(t, dtype, name):
+    if not t.is_cuda or t.dtype != dtype:
+        raise ValueError(f"{name}: expected a CUDA tensor of dtype {dtype}")
+    return t.contiguous()
+
+
+def regions_to_labels(probs, order=(1, 2, 3), bbox_lo=(0, 0, 0), full_shape=None):
+    """seg = 0; seg[probs[i] > 0.5] = order[i] in order; pasted at bbox_lo of a zero uint8 volume of
+    full_shape (reference driver :144-156, region_class_order=(1,2,3))."""
+    import torch
+    probs = _require_cuda(probs, torch.float32, "probs")
+    c, z, y, x = probs.shape
+    full = tuple(full_shape) if full_shape is not None else (z, y, x)
+    out = torch.empty(full, dtype=torch.uint8, device=probs.device)
+    order_a = (C.c_int32 * len(order))(*[int(v) for v in order])
+    lo = (C.c_int32 * 3)(*[int(v) for v in bbox_lo])
+    fu = (C.c_int32 * 3)(*[int(v) for v in full])
+    _lib.check(_lib.load().mi355_regions_to_labels(probs.data_ptr(), c, z, y, x, order_a, lo, fu, out.data_ptr(),
+                                                   _stream(probs)), "mi355_regions_to_labels")
+    return out
+
+
+def label_ensemble(a, b):
+    """uint8(np.round((a + b) / 2.0)) - the reference's 2-model label ensemble (driver :305)."""
+    import torch
+    a = _require_cuda(a, torch.uint8, "a")
+    b = _require_cuda(b, torch.uint8, "b")
+    if a.shape != b.shape:
+        raise ValueError("label_ensemble: shape mismatch")
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().mi355_label_ensemble(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream(a)),
+               "mi355_label_ensemble")
+    return out
+
+
+def prob_mean(a, b):
+    import torch
+    a = _require_cuda(a, torch.float32, "a")
+    b = _require_cuda(b, torch.float32, "b")
+    if a.shape != b.shape:
+        raise ValueError("prob_mean: shape mismatch")
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().mi355_prob_mean(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream(a)),
+               "mi355_prob_mean")
+    return out
+
+
+def zscore_masked_(vol, mask):
+    """In place: per channel x[m] = (x[m]-mean)/(std+1e-8), x[~m] = 0 (nonCT + use_mask_for_norm)."""
+    import torch
+    if not (vol.is_cuda and vol.dtype == torch.float32 and vol.is_contiguous()):
+        raise ValueError("zscore_masked_: vol must be a contiguous CUDA fp32 tensor")
+    mask = _require_cuda(mask, torch.uint8, "mask")
+    c = vol.shape[0]
+    v = vol[0].numel()
+    if mask.numel() != v:
+        raise ValueError("zscore_masked_: mask shape mismatch")
+    _lib.check(_lib.load().mi355_zscore_masked(vol.data_ptr(), mask.data_ptr(), c, v, _stream(vol)),
+               "mi355_zscore_masked")
+    return vol
+
+
+def conv3d_ndhwc(x, weight, bias=None, stride=1, act=0, slope=0.01, impl="mfma"):
+    """Single conv (test entry point). x: CUDA fp32 [N,D,H,W,Cin]; weight: numpy [Cout,Cin,3,3,3]."""
+    import torch
+    x = _require_cuda(x, torch.float32, "x")
+    n, d, h, w, cin = x.shape
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    cout = weight.shape[0]
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    do, ho, wo = (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1
+    y = torch.empty((n, do, ho, wo, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mi355_conv3d_ndhwc(x.data_ptr(), n, d, h, w, cin, _lib.fptr(weight), _lib.fptr(b), cout,
+                                              stride, act, slope, {"mfma": 0, "direct": 1}[impl], y.data_ptr(),
+                                              _stream(x)), "mi355_conv3d_ndhwc")
+    return y
+
+
+def tconv3d_ndhwc(x, weight):
+    """Single ConvTranspose3d k=2 s=2 (test entry point). weight: numpy [Cin,Cout,2,2,2]."""
+    import torch
+    x = _require_cuda(x, torch.float32, "x")
+    n, d, h, w, cin = x.shape
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    cout = weight.shape[1]
+    y = torch.empty((n, 2 * d, 2 * h, 2 * w, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mi355_tconv3d_ndhwc(x.data_ptr(), n, d, h, w, cin, _lib.fptr(weight), cout, y.data_ptr(),
+                                               _stream(x)), "mi355_tconv3d_ndhwc")
+    return y
+
+
+def compute_steps(patch, image, step_size):
+    buf = (C.c_int32 * 256)()
+    n = _lib.load().mi355_compute_steps(int(patch), int(image), float(step_size), buf, 256)
+    _lib.check(n, "mi355_compute_steps")
+    return [int(buf[i]) for i in range(n)]

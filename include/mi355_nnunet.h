@@ -1,0 +1,157 @@
+/*
+ * mi355_nnunet.h - C ABI of the MI355X-native nnU-Net (BraTS) sliding-window predictor.
+ *
+ * This is the drop-in boundary for the one hot path of the reference
+ * (SURVEY.md section 8b).  The reference is pure Python; what a maintainer would bind
+ * is a ctypes stub (INTEGRATION.md shows it).  Each entry point names the reference
+ * interface it replaces (paths relative to the reference repo):
+ *
+ *   mi355_unet_create        model_architecture/generic_UNet.py:188-421  Generic_UNet.__init__
+ *                            + nnunet load_model_and_checkpoint_files / trainer.load_checkpoint_ram
+ *                              as called at run_brats2021_inference_singlethread.py:178-183,95,113
+ *   mi355_unet_forward       model_architecture/generic_UNet.py:423-446  Generic_UNet.forward
+ *   mi355_sw_predict         trainer.predict_preprocessed_data_return_seg_and_softmax(...)[1]
+ *                            called at run_brats2021_inference_singlethread.py:97-106,114-123
+ *                            (+ the fold mean at :128 when several handles are given)
+ *   mi355_regions_to_labels  save_segmentation_nifti_from_softmax(..., region_class_order=(1,2,3))
+ *                            called at run_brats2021_inference_singlethread.py:144-156
+ *   mi355_label_ensemble     run_brats2021_inference_singlethread.py:299-305  np.round((s1+s2)/2)
+ *   mi355_prob_mean_threshold archived/kaist_original_inference.py:30-32 (nnUNet_ensemble mode)
+ *   mi355_zscore_masked      trainer.preprocess_patient -> nonCT + use_mask_for_norm normalisation,
+ *                            called at run_brats2021_inference_singlethread.py:89
+ *
+ * Conventions: every function returns 0 on success and a negative code on failure;
+ * mi355_last_error() gives the message of the calling thread's last failure.
+ * All "dev" pointers are device (HBM) pointers on the current HIP device; the caller
+ * owns them.  The library owns its weights and activation arena.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  One handle per (device, model);
+ * a handle must not be used from two threads at once.  There is NO CPU fallback: on a
+ * machine without a gfx950 device every compute entry point fails with MI355_ERR_NO_DEVICE.
+ */
+#ifndef MI355_NNUNET_H
+#define MI355_NNUNET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK 0
+#define MI355_ERR_INVALID (-1)
+#define MI355_ERR_HIP (-2)
+#define MI355_ERR_NO_DEVICE (-3)
+#define MI355_ERR_UNSUPPORTED (-4)
+
+enum { MI355_NORM_NONE = 0, MI355_NORM_BATCH = 1, MI355_NORM_INSTANCE = 2, MI355_NORM_GROUP = 3 };
+enum { MI355_F32 = 0, MI355_F16 = 1 };
+enum { MI355_NONLIN_IDENTITY = 0, MI355_NONLIN_SIGMOID = 1, MI355_NONLIN_SOFTMAX = 2 };
+
+/* One ConvDropoutNormNonlin block (generic_UNet.py:27-72): Conv3d k=3 p=1 + norm + LeakyReLU.
+ * All pointers are HOST pointers to fp32 data in the PyTorch layouts; they are read
+ * during mi355_unet_create only. */
+typedef struct {
+    int32_t cin, cout, stride;
+    const float *weight;       /* [cout][cin][3][3][3] */
+    const float *bias;         /* [cout] or NULL */
+    const float *gamma, *beta; /* norm affine [cout]; NULL -> 1 / 0 */
+    const float *running_mean, *running_var; /* MI355_NORM_BATCH only */
+} mi355_conv_desc;
+
+/* ConvTranspose3d k=2 s=2 bias=False (generic_UNet.py:363-364). */
+typedef struct {
+    int32_t cin, cout;
+    const float *weight; /* [cin][cout][2][2][2] */
+} mi355_tconv_desc;
+
+/* seg_outputs[-1]: Conv3d 1x1x1 (generic_UNet.py:389-391). */
+typedef struct {
+    int32_t cin, num_classes;
+    const float *weight; /* [num_classes][cin] */
+    const float *bias;   /* [num_classes] or NULL (seg_output_use_bias=False) */
+} mi355_head_desc;
+
+typedef struct {
+    int32_t in_channels, num_classes, num_pool;
+    int32_t norm;       /* MI355_NORM_* ; BATCH is eval mode and is folded into the conv */
+    int32_t num_groups; /* MI355_NORM_GROUP */
+    float eps, lrelu_slope;
+    int32_t nonlin_first; /* 1 = ConvDropoutNonlinNorm (generic_UNet.py:75-80) */
+    int32_t dtype;        /* MI355_F32 | MI355_F16 (storage; accumulation is always fp32) */
+    const int32_t *enc_convs; /* [num_pool+1] convs per encoder stage; last = bottleneck */
+    const int32_t *dec_convs; /* [num_pool]   convs per decoder stage */
+    const mi355_conv_desc *convs; /* execution order: encoder stages, bottleneck, decoder stages */
+    int32_t n_convs;
+    const mi355_tconv_desc *tconvs; /* [num_pool] */
+    mi355_head_desc head;
+} mi355_unet_desc;
+
+typedef struct mi355_unet *mi355_unet_t;
+
+typedef struct {
+    int32_t patch[3];     /* (z,y,x), e.g. 128,128,128 */
+    float step_size;      /* 0.5 */
+    int32_t use_gaussian; /* 1 */
+    int32_t mirror_axes;  /* bit0 = z, bit1 = y, bit2 = x; 7 = 8-way TTA, 0 = no TTA */
+    int32_t nonlin;       /* MI355_NONLIN_* applied to the logits of every forward */
+    int32_t batch_tiles;  /* tiles per forward pass (0 = choose) */
+} mi355_sw_opts;
+
+const char *mi355_last_error(void);
+int mi355_version(void);
+/* number of visible gfx950 devices (0 if none / no HIP runtime device) */
+int mi355_device_count(void);
+
+int mi355_unet_create(const mi355_unet_desc *desc, mi355_unet_t *out);
+int mi355_unet_destroy(mi355_unet_t net);
+/* 2*MAC of every conv / transposed conv evaluated per forward of one [d,h,w] patch. */
+int64_t mi355_unet_flops(mi355_unet_t net, int d, int h, int w);
+
+/* x_dev: [n][in_channels][d][h][w] fp32 (NCDHW, as the reference module takes it).
+ * logits_dev: [n][num_classes][d][h][w] fp32. */
+int mi355_unet_forward(mi355_unet_t net, const float *x_dev, int n, int d, int h, int w,
+                       float *logits_dev, void *stream);
+
+/* Sliding-window prediction of one preprocessed volume.
+ * vol_dev: [in_channels][Z][Y][X] fp32; probs_dev: [num_classes][Z][Y][X] fp32.
+ * With n_nets > 1 the result is the arithmetic mean over the handles (folds), summed in
+ * handle order (run_brats2021_inference_singlethread.py:128). */
+int mi355_sw_predict(const mi355_unet_t *nets, int n_nets, const float *vol_dev, int Z, int Y, int X,
+                     const mi355_sw_opts *opts, float *probs_dev, void *stream);
+/* Host helper: the step table the predictor uses (nnU-Net v1 _compute_steps_for_sliding_window).
+ * Writes at most max_steps entries, returns the count (or <0). */
+int mi355_compute_steps(int patch, int image, float step_size, int32_t *steps, int max_steps);
+/* Tile-sharded variant for multi-GPU: only tiles with (index % world) == rank are evaluated;
+ * agg_dev [num_classes][Zp][Yp][Xp] receives the Gaussian-weighted partial sums (to be summed
+ * across ranks in rank order), cnt_dev [Zp][Yp][Xp] the full normaliser. Zp.. = max(Z, patch). */
+int mi355_sw_partial(mi355_unet_t net, const float *vol_dev, int Z, int Y, int X,
+                     const mi355_sw_opts *opts, int rank, int world, float *agg_dev, float *cnt_dev,
+                     void *stream);
+int mi355_sw_finish(const float *agg_dev, const float *cnt_dev, int num_classes, int Z, int Y, int X,
+                    const int32_t patch[3], float *probs_dev, void *stream);
+
+/* seg = 0; for i in 0..C-1: seg[probs[i] > 0.5] = order[i]; pasted at bbox_lo into a zeroed
+ * [full_z][full_y][full_x] uint8 volume. */
+int mi355_regions_to_labels(const float *probs_dev, int C, int Z, int Y, int X, const int32_t *order,
+                            const int32_t bbox_lo[3], const int32_t full[3], uint8_t *labels_dev,
+                            void *stream);
+/* out = uint8(round_half_even((a + b) / 2)) elementwise. */
+int mi355_label_ensemble(const uint8_t *a_dev, const uint8_t *b_dev, uint8_t *out_dev, int64_t n,
+                         void *stream);
+/* probs_out = (a + b) / 2 (nnUNet_ensemble mode). */
+int mi355_prob_mean(const float *a_dev, const float *b_dev, float *out_dev, int64_t n, void *stream);
+/* Per channel: x[m] = (x[m]-mean(x[m]))/(std(x[m])+1e-8) ; x[~m] = 0  (m = mask != 0, ddof 0). */
+int mi355_zscore_masked(float *vol_dev, const uint8_t *mask_dev, int C, int64_t voxels, void *stream);
+
+/* Single-op entry points (used by the parity tests; same kernels the network runs).
+ * NDHWC fp32 device tensors. act: 0 none, 1 LeakyReLU(slope). */
+int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
+                       const float *bias_host, int cout, int stride, int act, float slope, int impl,
+                       float *y_dev, void *stream);
+int mi355_tconv3d_ndhwc(const float *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
+                        int cout, float *y_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_NNUNET_H */

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def amd():
+    import brats_amd
+    return brats_amd
+
+
+@pytest.fixture(scope="session")
+def gpu(amd):
+    """The HIP path or nothing: GPU tests fail (not skip) if the extension or the device is missing."""
+    import torch
+    assert torch.cuda.is_available(), "GPU test collected on a machine without a GPU"
+    lib = amd._lib.load()
+    assert lib.mi355_device_count() > 0
+    return torch.device("cuda:0")

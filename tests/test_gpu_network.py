@@ -1,0 +1,121 @@
+"""-m gpu: whole-network and sliding-window parity of the HIP path against the CPU oracle
+(oracle/unet_ref.py is itself pinned to the reference module, see tests/test_oracle_*.py).
+
+Tolerances (BASELINE.json north_star): probabilities within 1e-3 of the fp32 CPU path, Dice of
+the label maps >= 0.999.  Logits are also bounded relative to their spread, a much tighter check."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tiler_ref, unet_ref
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-3
+
+
+def _check_logits(got, ref):
+    spread = float(ref.std())
+    err = float(np.abs(got - ref).max())
+    perr = float(np.abs(1 / (1 + np.exp(-got.astype(np.float64))) - 1 / (1 + np.exp(-ref.astype(np.float64)))).max())
+    assert err <= 2e-4 * max(spread, 1.0), f"logit max abs err {err} (spread {spread})"
+    assert perr <= PROB_TOL, f"sigmoid prob err {perr}"
+
+
+@pytest.mark.parametrize("name", ["A", "A_in", "B"])
+def test_forward_64_matches_oracle(amd, gpu, name):
+    sd, meta = amd.synthetic.make_model(name, seed=7)
+    net = amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"])
+    x = np.random.RandomState(1).standard_normal((1, 4, 64, 64, 64)).astype(np.float32)
+    ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])).numpy()
+    got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
+    _check_logits(got, ref)
+    net.close()
+
+
+def test_forward_batch_and_ragged_patch(amd, gpu):
+    """Batch of 3 with a non-cubic patch (32 x 64 x 96): per-sample InstanceNorm statistics."""
+    sd, meta = amd.synthetic.make_model("A_in", seed=3, num_pool=3, max_feat=128)
+    net = amd.UNet(sd, norm="instance")
+    x = np.random.RandomState(4).standard_normal((3, 4, 32, 64, 96)).astype(np.float32)
+    ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm="instance")).numpy()
+    got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
+    _check_logits(got, ref)
+
+
+def test_forward_nonlin_first_variants(amd, gpu):
+    """ConvDropoutNonlinNorm ordering (generic_UNet.py:75-80) with GroupNorm and BatchNorm."""
+    for norm in ("group", "batch"):
+        sd, _ = amd.synthetic.make_model("A", seed=5, num_pool=2, max_feat=64, norm=norm)
+        net = amd.UNet(sd, norm=norm, num_groups=8, nonlin_first=True)
+        x = np.random.RandomState(6).standard_normal((2, 4, 16, 16, 32)).astype(np.float32)
+        ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm=norm, num_groups=8, nonlin_first=True)).numpy()
+        got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
+        _check_logits(got, ref)
+
+
+def test_forward_128_model_a(amd, gpu):
+    """Full-size patch of the bench model (BASELINE.json configs[1]); flop count cross-check."""
+    sd, meta = amd.synthetic.make_model("A", seed=7)
+    net = amd.UNet(sd, norm="batch")
+    assert net.flops((128, 128, 128)) == unet_ref.conv_flops(sd, (128, 128, 128)) == net.topology.conv_flops((128, 128, 128))
+    x = np.random.RandomState(2).standard_normal((1, 4, 128, 128, 128)).astype(np.float32)
+    ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm="batch")).numpy()
+    got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
+    _check_logits(got, ref)
+
+
+def _small_net(amd, norm="batch", seed=21):
+    sd, _ = amd.synthetic.make_model("A", seed=seed, num_pool=2, max_feat=128, norm=norm)
+    return sd
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(shape=(40, 56, 44), mirror=True, gaussian=True, nonlin="sigmoid"),    # 2x2x2 tiles, 8-way TTA
+    dict(shape=(32, 70, 32), mirror=False, gaussian=True, nonlin="sigmoid"),   # 1x4x1 tiles, no TTA
+    dict(shape=(20, 40, 30), mirror=True, gaussian=True, nonlin="softmax"),    # padded in z and x; softmax head
+    dict(shape=(32, 32, 32), mirror=True, gaussian=True, nonlin="sigmoid"),    # single tile -> no gaussian
+    dict(shape=(48, 33, 47), mirror=True, gaussian=False, nonlin="sigmoid", axes=(0, 2)),  # 4-way TTA subset
+])
+def test_sliding_window_matches_oracle(amd, gpu, cfg):
+    sd = _small_net(amd)
+    net = amd.UNet(sd, norm="batch")
+    patch = (32, 32, 32)
+    rs = np.random.RandomState(31)
+    vol = rs.standard_normal((4,) + cfg["shape"]).astype(np.float32)
+    axes = cfg.get("axes", (0, 1, 2))
+    ref = tiler_ref.predict_3d_tiled(tiler_ref.make_net_fn(sd, unet_ref.default_cfg("batch")), vol, patch, 3, 0.5,
+                                     cfg["mirror"], axes, cfg["gaussian"], cfg["nonlin"])
+    got = amd.predictor.predict_folds([net], vol, patch, 0.5, cfg["mirror"], axes, cfg["gaussian"], cfg["nonlin"])
+    got = got.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= PROB_TOL
+    if cfg["nonlin"] == "sigmoid":
+        d = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(got), tiler_ref.regions_to_labels(ref))
+        assert d["mean"] >= 0.999
+    # batching tiles differently must not change the result beyond fp32 noise
+    got2 = amd.predictor.predict_folds([net], vol, patch, 0.5, cfg["mirror"], axes, cfg["gaussian"], cfg["nonlin"],
+                                       batch_tiles=1).cpu().numpy()
+    assert np.abs(got2 - got).max() <= 1e-6
+
+
+def test_fold_mean_and_tile_sharding(amd, gpu):
+    sds = [_small_net(amd, seed=s) for s in (21, 22, 23)]
+    nets = [amd.UNet(sd, norm="batch") for sd in sds]
+    patch = (32, 32, 32)
+    vol = np.random.RandomState(8).standard_normal((4, 40, 48, 36)).astype(np.float32)
+    per_fold = [tiler_ref.predict_3d_tiled(tiler_ref.make_net_fn(sd, unet_ref.default_cfg("batch")), vol, patch, 3)
+                for sd in sds]
+    ref = np.mean(per_fold, axis=0)  # driver :128
+    got = amd.predictor.predict_folds(nets, vol, patch).cpu().numpy()
+    assert np.abs(got - ref).max() <= PROB_TOL
+    # tile-sharded path (what N ranks would do), summed in rank order
+    world = 3
+    parts = [amd.predictor.predict_tile_sharded(nets[0], vol, r, world, patch) for r in range(world)]
+    agg = parts[0][0].clone()
+    for r in range(1, world):
+        agg += parts[r][0]
+    probs = amd.predictor.finish_sharded(agg, parts[0][1], vol.shape[1:], patch).cpu().numpy()
+    assert np.abs(probs - per_fold[0]).max() <= PROB_TOL
+    for r in range(1, world):
+        assert torch.equal(parts[r][1], parts[0][1])  # every rank holds the same normaliser

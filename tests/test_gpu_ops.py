@@ -1,0 +1,136 @@
+"""-m gpu: single-kernel parity through the C ABI against torch-CPU fp32 (the reference's own
+backend, L0 in SURVEY.md section 1).  Tolerances are for fp32 summation-order differences only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(rs, *shape):
+    return rs.standard_normal(shape).astype(np.float32)
+
+
+def _ref_conv(x_ndhwc, w, b, stride, act, slope):
+    x = torch.from_numpy(x_ndhwc).permute(0, 4, 1, 2, 3).contiguous()
+    y = F.conv3d(x, torch.from_numpy(w), None if b is None else torch.from_numpy(b), stride=stride, padding=1)
+    if act:
+        y = F.leaky_relu(y, slope)
+    return y.permute(0, 2, 3, 4, 1).contiguous().numpy()
+
+
+CONV_CASES = [
+    # n, d, h, w, cin, cout, stride, act
+    (1, 16, 16, 32, 32, 32, 1, 0),     # the dominant shape class (Cin=Cout=32), one x-row of tiles
+    (2, 8, 12, 40, 16, 64, 1, 1),      # ragged dims (partial tiles in y and x), NF=2, fused LeakyReLU, batch
+    (1, 8, 8, 8, 8, 32, 1, 0),         # stem-like Cin=8 (CC=8 path)
+    (1, 4, 4, 4, 64, 96, 1, 1),        # tiny volume, Cout=96 (NF=1, 3 cout blocks)
+    (1, 16, 16, 32, 32, 64, 2, 0),     # stride 2
+    (2, 10, 6, 14, 64, 32, 2, 1),      # stride 2, ragged / odd output dims
+    (1, 32, 32, 32, 64, 64, 1, 0),     # several chunks (4 x 16 channels), many tiles
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_mfma_matches_torch(amd, gpu, case):
+    n, d, h, w, cin, cout, stride, act = case
+    rs = np.random.RandomState(hash(case) % (2 ** 31))
+    x = _rand(rs, n, d, h, w, cin)
+    wt = _rand(rs, cout, cin, 3, 3, 3) / np.sqrt(cin * 27)
+    b = _rand(rs, cout)
+    ref = _ref_conv(x, wt, b, stride, act, 0.01)
+    y = amd.ops.conv3d_ndhwc(torch.from_numpy(x).to(gpu), wt, b, stride=stride, act=act, slope=0.01, impl="mfma")
+    y = y.cpu().numpy()
+    assert y.shape == ref.shape
+    err = np.abs(y - ref).max()
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), f"max abs err {err}"
+
+
+@pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[5], (1, 6, 5, 7, 5, 7, 1, 1)])
+def test_conv3d_direct_matches_torch(amd, gpu, case):
+    n, d, h, w, cin, cout, stride, act = case
+    rs = np.random.RandomState(11)
+    x = _rand(rs, n, d, h, w, cin)
+    if cin % 4:  # NDHWC tensors are channel-padded to a multiple of 4 by their producers
+        pad = 4 - cin % 4
+        xp = np.concatenate([x, np.zeros((n, d, h, w, pad), np.float32)], -1)
+    else:
+        xp = x
+    wt = _rand(rs, cout, cin, 3, 3, 3) / np.sqrt(cin * 27)
+    ref = _ref_conv(x, wt, None, stride, act, 0.01)
+    wt_p = np.zeros((cout, xp.shape[-1], 3, 3, 3), np.float32)
+    wt_p[:, :cin] = wt
+    y = amd.ops.conv3d_ndhwc(torch.from_numpy(xp).to(gpu), wt_p, None, stride=stride, act=act, impl="direct").cpu().numpy()
+    assert np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_conv3d_mfma_identity_asymmetric(amd, gpu):
+    """Exact-integer check of the MFMA operand / accumulator maps: a centre-tap weight that maps
+    channel c -> output (3c+1) % 32 with distinct integer gains must reproduce the input exactly."""
+    rs = np.random.RandomState(3)
+    x = rs.randint(-8, 9, size=(1, 8, 8, 32, 32)).astype(np.float32)
+    wt = np.zeros((32, 32, 3, 3, 3), np.float32)
+    for c in range(32):
+        wt[(3 * c + 1) % 32, c, 1, 1, 1] = float(c + 1)
+    y = amd.ops.conv3d_ndhwc(torch.from_numpy(x).to(gpu), wt, None).cpu().numpy()
+    ref = np.zeros_like(y)
+    for c in range(32):
+        ref[..., (3 * c + 1) % 32] = x[..., c] * (c + 1)
+    assert np.array_equal(y, ref)
+
+
+@pytest.mark.parametrize("case", [(1, 4, 4, 4, 32, 32), (2, 3, 5, 6, 64, 32), (1, 8, 8, 8, 320, 320), (1, 2, 2, 2, 256, 512)])
+def test_tconv_matches_torch(amd, gpu, case):
+    n, d, h, w, cin, cout = case
+    rs = np.random.RandomState(5)
+    x = _rand(rs, n, d, h, w, cin)
+    wt = _rand(rs, cin, cout, 2, 2, 2) / np.sqrt(cin)
+    ref = F.conv_transpose3d(torch.from_numpy(x).permute(0, 4, 1, 2, 3), torch.from_numpy(wt), None, stride=2)
+    ref = ref.permute(0, 2, 3, 4, 1).contiguous().numpy()
+    y = amd.ops.tconv3d_ndhwc(torch.from_numpy(x).to(gpu), wt).cpu().numpy()
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_label_ensemble_truth_table(amd, gpu):
+    """np.round((s1+s2)/2) - half to even (reference driver :305)."""
+    a, b = np.meshgrid(np.arange(5, dtype=np.uint8), np.arange(5, dtype=np.uint8), indexing="ij")
+    want = np.round((a.astype(np.float64) + b.astype(np.float64)) / 2.0).astype(np.uint8)
+    got = amd.ops.label_ensemble(torch.from_numpy(a.copy()).to(gpu), torch.from_numpy(b.copy()).to(gpu)).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert want[0, 3] == 2 and want[0, 1] == 0 and want[1, 2] == 2 and want[2, 3] == 2
+
+
+def test_regions_to_labels_and_paste(amd, gpu):
+    rs = np.random.RandomState(9)
+    probs = rs.uniform(0, 1, size=(3, 5, 6, 7)).astype(np.float32)
+    probs[0, 0, 0, 0] = 0.5  # not > 0.5
+    seg = np.zeros((5, 6, 7), np.uint8)
+    for i, c in enumerate((1, 2, 3)):
+        seg[probs[i] > 0.5] = c
+    want = np.zeros((9, 8, 10), np.uint8)
+    want[2:7, 1:7, 3:10] = seg
+    got = amd.ops.regions_to_labels(torch.from_numpy(probs).to(gpu), (1, 2, 3), (2, 1, 3), (9, 8, 10)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_zscore_masked(amd, gpu):
+    rs = np.random.RandomState(2)
+    vol = (rs.standard_normal((4, 9, 10, 11)) * 300 + 1000).astype(np.float32)
+    mask = rs.uniform(size=(9, 10, 11)) > 0.3
+    want = vol.copy()
+    for c in range(4):
+        mn, sd = want[c][mask].mean(), want[c][mask].std()
+        want[c][mask] = (want[c][mask] - mn) / (sd + 1e-8)
+        want[c][~mask] = 0
+    got = amd.ops.zscore_masked_(torch.from_numpy(vol).to(gpu), torch.from_numpy(mask.astype(np.uint8)).to(gpu)).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5
+    assert np.all(got[:, ~mask] == 0)
+
+
+def test_compute_steps_table(amd):
+    """Host helper, no GPU needed for the call itself; kept here because it goes through the .so."""
+    assert amd.ops.compute_steps(128, 140, 0.5) == [0, 12]
+    assert amd.ops.compute_steps(128, 240, 0.5) == [0, 56, 112]
+    assert amd.ops.compute_steps(128, 128, 0.5) == [0]
