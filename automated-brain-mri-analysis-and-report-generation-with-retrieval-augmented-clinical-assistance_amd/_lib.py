@@ -23,7 +23,8 @@ EXPORTS = [
     "mi355_last_error", "mi355_version", "mi355_device_count", "mi355_unet_create", "mi355_unet_destroy",
     "mi355_unet_flops", "mi355_unet_forward", "mi355_sw_predict", "mi355_compute_steps", "mi355_sw_partial",
     "mi355_sw_finish", "mi355_regions_to_labels", "mi355_label_ensemble", "mi355_prob_mean",
-    "mi355_zscore_masked", "mi355_conv3d_ndhwc", "mi355_tconv3d_ndhwc",
+    "mi355_zscore_masked", "mi355_conv3d_ndhwc", "mi355_tconv3d_ndhwc", "mi355_profile_enable",
+    "mi355_profile_read",
 ]
 
 
@@ -53,6 +54,11 @@ class UNetDesc(C.Structure):
 class SwOpts(C.Structure):
     _fields_ = [("patch", C.c_int32 * 3), ("step_size", C.c_float), ("use_gaussian", C.c_int32),
                 ("mirror_axes", C.c_int32), ("nonlin", C.c_int32), ("batch_tiles", C.c_int32)]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
 
 
 class Mi355Error(RuntimeError):
@@ -94,6 +100,8 @@ def load():
     lib.mi355_conv3d_ndhwc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int,
                                        C.c_int, C.c_int, C.c_float, C.c_int, vp, vp]
     lib.mi355_tconv3d_ndhwc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, vp, vp]
+    lib.mi355_profile_enable.argtypes = [vp, C.c_int]
+    lib.mi355_profile_read.argtypes = [vp, C.POINTER(ProfEntry), C.c_int]
     _lib = lib
     return lib
 

@@ -55,6 +55,10 @@ struct mi355_unet {
     float *gauss_dev = nullptr;
     int gauss_p[3] = {0, 0, 0};
     int max_channels = 0;
+    // optional per-kernel HIP-event timing (bench.py roofline)
+    bool prof_on = false;
+    struct ProfRec { std::string name; double flops, bytes; hipEvent_t a, b; };
+    std::vector<ProfRec> prof;
 };
 
 namespace mi355 {
@@ -187,6 +191,26 @@ static int ensure_arena(mi355_unet *net, size_t bytes) {
     return MI355_OK;
 }
 
+struct ProfScope {
+    mi355_unet *net; hipStream_t s; bool on; size_t idx;
+    ProfScope(mi355_unet *n, hipStream_t st, const std::string &name, double flops, double bytes) : net(n), s(st), on(n->prof_on), idx(0) {
+        if (!on) return;
+        mi355_unet::ProfRec r; r.name = name; r.flops = flops; r.bytes = bytes;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(r.a, s);
+        idx = net->prof.size();
+        net->prof.push_back(r);
+    }
+    ~ProfScope() { if (on) (void)hipEventRecord(net->prof[idx].b, s); }
+};
+
+static std::string conv_kernel_name(const ConvWeights &w) {
+    if (!w.wp_dev) return "conv3_direct_kernel";
+    char buf[64];
+    snprintf(buf, sizeof(buf), "conv3_f32_mfma_kernel<%d, %d, %d, %d>", w.stride, w.cc, w.stride == 1 ? 2 : 1, w.nf);
+    return buf;
+}
+
 // One ConvDropoutNormNonlin / ConvDropoutNonlinNorm block.
 static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const float *in0, int C0,
                      const float *in1, int C1, int N, int Di, int Hi, int Wi, float *out, hipStream_t s) {
@@ -203,13 +227,20 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
     } else {
         c.act = ACT_LRELU;
     }
-    if (L.w.wp_dev) MI355_TRY(conv3d_mfma_f32(L.w, c, s));
-    else MI355_TRY(conv3d_direct_f32(L.w, c, s));
     const int st = L.stride;
     const int64_t Vo = (int64_t)((Di - 1) / st + 1) * ((Hi - 1) / st + 1) * ((Wi - 1) / st + 1);
+    {
+        // algorithmic work of this launch: 2*MAC over the LOGICAL cin; input read once + output written once + weights
+        const double flops = 2.0 * N * Vo * L.cout * (double)L.cin * 27.0;
+        const double bytes = 4.0 * ((double)N * Di * Hi * Wi * (C0 + C1) + (double)N * Vo * L.cout + (double)L.cout * L.cin * 27.0);
+        ProfScope ps(net, s, conv_kernel_name(L.w), flops, bytes);
+        if (L.w.wp_dev) MI355_TRY(conv3d_mfma_f32(L.w, c, s));
+        else MI355_TRY(conv3d_direct_f32(L.w, c, s));
+    }
     if (L.runtime_norm) {
         MI355_TRY(norm_finalize(stats, N, L.cout, Vo, net->norm, net->num_groups, net->eps, L.gamma_dev, L.beta_dev,
                                 scale, shift, s));
+        ProfScope ps(net, s, "norm_apply_kernel", 2.0 * N * Vo * L.cout, 8.0 * N * Vo * L.cout);
         MI355_TRY(norm_apply(out, N, Vo, L.cout, scale, shift, net->nonlin_first ? ACT_NONE : ACT_LRELU, net->slope, s));
     } else if (L.post_affine) {
         // BN after the nonlinearity: per-channel affine, identical for every sample
@@ -248,7 +279,12 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
         const int Dl = D >> l, Hl = H >> l, Wl = W >> l;
         float *up = buf(2, l);
         MI355_REQUIRE(net->tu[u].cin == curC, "tu.%d expects %d channels, got %d", u, net->tu[u].cin, curC);
-        MI355_TRY(tconv2_mfma_f32(net->tu[u], cur, N, Dl / 2, Hl / 2, Wl / 2, up, s));
+        {
+            const double vin = (double)N * (Dl / 2) * (Hl / 2) * (Wl / 2);
+            ProfScope ps(net, s, "tconv2_f32_mfma_kernel<2>", 2.0 * vin * net->tu[u].cin * net->tu[u].cout * 8.0,
+                         4.0 * (vin * net->tu[u].cin + 8.0 * vin * net->tu[u].cout + 8.0 * net->tu[u].cin * net->tu[u].cout));
+            MI355_TRY(tconv2_mfma_f32(net->tu[u], cur, N, Dl / 2, Hl / 2, Wl / 2, up, s));
+        }
         // concat order (upsampled, skip): generic_UNet.py:438 - never materialised
         const float *in0 = up, *in1 = skip[l];
         int C0 = net->tu[u].cout, C1 = skipC[l];
@@ -380,14 +416,21 @@ static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X,
                 td.mirror = g.mirrors[m];
                 samples.push_back(td);
             }
+        {
+        const double pv = (double)samples.size() * g.P[0] * g.P[1] * g.P[2];
+        ProfScope ps(net, s, "extract_tiles_kernel", 0.0, 4.0 * pv * (net->in_channels + net->cin_pad));
         MI355_TRY(extract_tiles(vol, net->in_channels, Z, Y, X, g.pad_lo[0], g.pad_lo[1], g.pad_lo[2], samples.data(),
                                 (int)samples.size(), g.P[0], g.P[1], g.P[2], net->cin_pad,
                                 (float *)(net->arena + pl.x0_off), s));
+        }
         const float *feat; int fc;
         MI355_TRY(forward_features(net, pl, (int)samples.size(), g.P[0], g.P[1], g.P[2], &feat, &fc, s));
         MI355_REQUIRE(fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
         for (int i = 0; i < nb; ++i) {
             const TileDesc &td = g.tiles[mine[b0 + i]];
+            const double pv = (double)g.P[0] * g.P[1] * g.P[2];
+            ProfScope ps(net, s, "head_aggregate_kernel", 2.0 * pv * nm * fc * net->num_classes,
+                         4.0 * pv * (nm * fc + 2.0 * net->num_classes + 3.0));
             MI355_TRY(head_aggregate(net->head, feat, i * nm, g.mirrors.data(), nm, g.P[0], g.P[1], g.P[2], o.nonlin,
                                      use_gauss ? net->gauss_dev : nullptr, agg, (cnt && world == 1) ? cnt : nullptr,
                                      g.Zp[0], g.Zp[1], g.Zp[2], td.z0, td.y0, td.x0, s));
@@ -509,6 +552,36 @@ extern "C" int mi355_unet_forward(mi355_unet_t net, const float *x_dev, int n, i
     MI355_REQUIRE(fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
     MI355_TRY(head_logits(net->head, feat, n, V, logits_dev, s));
     return MI355_OK;
+}
+
+extern "C" int mi355_profile_enable(mi355_unet_t net, int on) {
+    MI355_REQUIRE(net, "null handle");
+    net->prof_on = on != 0;
+    return MI355_OK;
+}
+
+// Synchronises the device, folds the recorded launches per kernel name, clears the log.
+extern "C" int mi355_profile_read(mi355_unet_t net, mi355_prof_entry *out, int max_entries) {
+    MI355_REQUIRE(net && out && max_entries > 0, "bad argument");
+    MI355_HIP(hipDeviceSynchronize());
+    int n = 0;
+    for (auto &r : net->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+        int k = 0;
+        for (; k < n; ++k) if (r.name == out[k].name) break;
+        if (k == n) {
+            if (n == max_entries) continue;
+            memset(&out[n], 0, sizeof(out[n]));
+            snprintf(out[n].name, sizeof(out[n].name), "%s", r.name.c_str());
+            ++n;
+        }
+        out[k].launches += 1; out[k].ms += ms; out[k].flops += r.flops; out[k].bytes += r.bytes;
+    }
+    net->prof.clear();
+    return n;
 }
 
 extern "C" int mi355_compute_steps(int patch, int image, float step_size, int32_t *steps, int max_steps) {

@@ -203,6 +203,17 @@ class UNet:
     def flops(self, patch) -> int:
         return int(_lib.load().mi355_unet_flops(self.handle, int(patch[0]), int(patch[1]), int(patch[2])))
 
+    def profile(self, on: bool = True):
+        """Per-kernel HIP-event timing of every launch made through this handle (bench.py)."""
+        _lib.check(_lib.load().mi355_profile_enable(self.handle, int(on)), "mi355_profile_enable")
+
+    def read_profile(self):
+        buf = (_lib.ProfEntry * 32)()
+        n = _lib.load().mi355_profile_read(self.handle, buf, 32)
+        _lib.check(n, "mi355_profile_read")
+        return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), ms=float(buf[i].ms),
+                     flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(n)]
+
     def forward(self, x):
         """x: torch.cuda fp32 [N, C, D, H, W] -> logits [N, num_classes, D, H, W] (final_nonlin = identity)."""
         import torch

@@ -143,6 +143,16 @@ int mi355_prob_mean(const float *a_dev, const float *b_dev, float *out_dev, int6
 /* Per channel: x[m] = (x[m]-mean(x[m]))/(std(x[m])+1e-8) ; x[~m] = 0  (m = mask != 0, ddof 0). */
 int mi355_zscore_masked(float *vol_dev, const uint8_t *mask_dev, int C, int64_t voxels, void *stream);
 
+/* Per-kernel timing with HIP events on the stream the kernels are launched on (bench.py's
+ * roofline). flops / bytes are the ALGORITHMIC work of the recorded launches. */
+typedef struct {
+    char name[64];
+    int64_t launches;
+    double ms, flops, bytes;
+} mi355_prof_entry;
+int mi355_profile_enable(mi355_unet_t net, int on);
+int mi355_profile_read(mi355_unet_t net, mi355_prof_entry *out, int max_entries);
+
 /* Single-op entry points (used by the parity tests; same kernels the network runs).
  * NDHWC fp32 device tensors. act: 0 none, 1 LeakyReLU(slope). */
 int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,

@@ -37,7 +37,7 @@ def test_conv3d_mfma_matches_torch(amd, gpu, case):
     n, d, h, w, cin, cout, stride, act = case
     rs = np.random.RandomState(hash(case) % (2 ** 31))
     x = _rand(rs, n, d, h, w, cin)
-    wt = _rand(rs, cout, cin, 3, 3, 3) / np.sqrt(cin * 27)
+    wt = (_rand(rs, cout, cin, 3, 3, 3) / np.sqrt(cin * 27)).astype(np.float32)
     b = _rand(rs, cout)
     ref = _ref_conv(x, wt, b, stride, act, 0.01)
     y = amd.ops.conv3d_ndhwc(torch.from_numpy(x).to(gpu), wt, b, stride=stride, act=act, slope=0.01, impl="mfma")
@@ -57,7 +57,7 @@ def test_conv3d_direct_matches_torch(amd, gpu, case):
         xp = np.concatenate([x, np.zeros((n, d, h, w, pad), np.float32)], -1)
     else:
         xp = x
-    wt = _rand(rs, cout, cin, 3, 3, 3) / np.sqrt(cin * 27)
+    wt = (_rand(rs, cout, cin, 3, 3, 3) / np.sqrt(cin * 27)).astype(np.float32)
     ref = _ref_conv(x, wt, None, stride, act, 0.01)
     wt_p = np.zeros((cout, xp.shape[-1], 3, 3, 3), np.float32)
     wt_p[:, :cin] = wt
@@ -85,7 +85,7 @@ def test_tconv_matches_torch(amd, gpu, case):
     n, d, h, w, cin, cout = case
     rs = np.random.RandomState(5)
     x = _rand(rs, n, d, h, w, cin)
-    wt = _rand(rs, cin, cout, 2, 2, 2) / np.sqrt(cin)
+    wt = (_rand(rs, cin, cout, 2, 2, 2) / np.sqrt(cin)).astype(np.float32)
     ref = F.conv_transpose3d(torch.from_numpy(x).permute(0, 4, 1, 2, 3), torch.from_numpy(wt), None, stride=2)
     ref = ref.permute(0, 2, 3, 4, 1).contiguous().numpy()
     y = amd.ops.tconv3d_ndhwc(torch.from_numpy(x).to(gpu), wt).cpu().numpy()
