@@ -1,0 +1,89 @@
+"""not gpu: host-side logic of the product and the C-ABI surface (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import tiler_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(amd):
+    hdr = open(os.path.join(ROOT, "include", "mi355_nnunet.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(amd._lib.EXPORTS), declared ^ set(amd._lib.EXPORTS)
+    lib = ctypes.CDLL(str(amd._lib.lib_path()))
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} not exported"
+    assert lib.mi355_version() >= 100
+
+
+def test_compute_steps_in_library_matches_oracle(amd):
+    """mi355_compute_steps is host code in the .so: callable without a GPU."""
+    for img in list(range(128, 262)) + [300, 511]:
+        want = tiler_ref.compute_steps_for_sliding_window((128,), (img,), 0.5)[0]
+        assert amd.ops.compute_steps(128, img, 0.5) == want, img
+    for patch, img, step in [(32, 70, 0.5), (64, 64, 0.5), (96, 200, 0.25), (128, 240, 1.0), (40, 57, 0.75)]:
+        assert amd.ops.compute_steps(patch, img, step) == tiler_ref.compute_steps_for_sliding_window((patch,), (img,), step)[0]
+    with pytest.raises(amd._lib.Mi355Error):
+        amd.ops.compute_steps(128, 100, 0.5)  # image smaller than the patch: caller must pad first
+
+
+def test_topology_from_state_dict_model_a_and_b(amd):
+    sd, _ = amd.synthetic.make_model("A")
+    t = amd.topology_from_state_dict(sd)
+    assert (t.in_channels, t.num_classes, t.num_pool, t.head_cin) == (4, 3, 5, 32)
+    assert [[(c.cin, c.cout, c.stride) for c in st] for st in t.enc] == [
+        [(4, 32, 1), (32, 32, 1)], [(32, 64, 2), (64, 64, 1)], [(64, 128, 2), (128, 128, 1)],
+        [(128, 256, 2), (256, 256, 1)], [(256, 320, 2), (320, 320, 1)], [(320, 320, 2), (320, 320, 1)]]
+    assert t.tu == [(320, 320), (320, 256), (256, 128), (128, 64), (64, 32)]
+    assert [(st[0].cin, st[-1].cout) for st in t.dec] == [(640, 320), (512, 256), (256, 128), (128, 64), (64, 32)]
+    assert t.has_batchnorm_stats
+    assert abs(t.conv_flops((128, 128, 128)) / 1e9 - 965.47) < 0.05
+    sd_b, _ = amd.synthetic.make_model("B")
+    tb = amd.topology_from_state_dict({"module." + k: v for k, v in sd_b.items()})  # DataParallel prefix
+    # irregular decoder of encoder_scale=2: tu.1 is 256->512, loc.1 is 1024->512->256
+    assert tb.tu[1] == (256, 512) and [(c.cin, c.cout) for c in tb.dec[1]] == [(1024, 512), (512, 256)]
+    assert tb.head_cin == 32 and not tb.has_batchnorm_stats
+    with pytest.raises(ValueError):
+        amd.topology_from_state_dict({**sd, "axial_attention.0.to_q.weight": np.zeros(1)})
+
+
+def test_synthetic_generators_are_frozen(amd):
+    sd, _ = amd.synthetic.make_model("A", seed=7)
+    w = sd["conv_blocks_context.0.blocks.0.conv.weight"]
+    assert w.dtype == np.float32 and w.shape == (32, 4, 3, 3, 3)
+    assert abs(float(w[0, 0, 0, 0, 0]) - 0.23003991) < 1e-6  # RandomState(7) stream
+    v = amd.synthetic.make_volume(seed=3, shape=(24, 32, 28))
+    assert v.shape == (4, 24, 32, 28) and v.dtype == np.float32 and (v == 0).any() and v.max() > 1000
+    v2 = amd.synthetic.make_volume(seed=3, shape=(24, 32, 28))
+    assert np.array_equal(v, v2)
+
+
+def test_no_gpu_means_loud_failure_not_fallback(amd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sd, meta = amd.synthetic.make_model("A", num_pool=2, max_feat=64)
+    with pytest.raises(amd._lib.Mi355Error, match="no HIP device|CPU fallback"):
+        amd.UNet(sd, norm="batch")
+    with pytest.raises(ValueError):
+        amd.UNet(amd.synthetic.make_model("A_in", num_pool=2, max_feat=64)[0], norm="auto")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "automated-brain-mri-analysis-and-report-generation-with-retrieval-augmented-clinical-assistance_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+    for f in ("run_brats2021_inference_singlethread.py",):
+        p = os.path.join(ROOT, f)
+        if os.path.exists(p):
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", open(p).read(), flags=re.M)
