@@ -48,9 +48,9 @@ struct mi355_unet {
     std::vector<std::vector<ConvLayer>> dec;  // num_pool stages
     std::vector<TConvWeights> tu;
     HeadWeights head;
-    // activation arena
+    // activation arena: ONE per process and device, shared by every handle (handles run one after
+    // the other on the caller's stream; 5 folds x 2 models would not fit 288 GB with private arenas)
     char *arena = nullptr;
-    size_t arena_bytes = 0;
     // gaussian importance map cache
     float *gauss_dev = nullptr;
     int gauss_p[3] = {0, 0, 0};
@@ -135,7 +135,6 @@ static void destroy(mi355_unet *net) {
     for (auto &st : net->dec) for (auto &L : st) free_conv(&L);
     for (auto &t : net->tu) tconv_weights_free(&t);
     head_weights_free(&net->head);
-    if (net->arena) (void)hipFree(net->arena);
     if (net->gauss_dev) (void)hipFree(net->gauss_dev);
     delete net;
 }
@@ -179,15 +178,20 @@ static int make_plan(const mi355_unet &net, int N, int D, int H, int W, Plan *pl
     return MI355_OK;
 }
 
+static char *g_arena = nullptr;
+static size_t g_arena_bytes = 0;
+
 static int ensure_arena(mi355_unet *net, size_t bytes) {
-    if (net->arena_bytes >= bytes) return MI355_OK;
-    if (net->arena) {
-        MI355_HIP(hipDeviceSynchronize());
-        MI355_HIP(hipFree(net->arena));
-        net->arena = nullptr; net->arena_bytes = 0;
+    if (g_arena_bytes < bytes) {
+        if (g_arena) {
+            MI355_HIP(hipDeviceSynchronize());
+            MI355_HIP(hipFree(g_arena));
+            g_arena = nullptr; g_arena_bytes = 0;
+        }
+        MI355_HIP(hipMalloc(&g_arena, bytes));
+        g_arena_bytes = bytes;
     }
-    MI355_HIP(hipMalloc(&net->arena, bytes));
-    net->arena_bytes = bytes;
+    net->arena = g_arena;
     return MI355_OK;
 }
 

@@ -1,0 +1,218 @@
+"""Drop-in mirror of the reference's hot-path driver, ``run_brats2021_inference_singlethread.py``.
+
+Function names, argument meaning, on-disk products and exit behaviour follow the reference file
+line for line (cited per function); the compute underneath is the HIP library.  The repo-root
+script of the same name calls ``main()`` here, so ``run_full_pipeline.py:162-168`` works unchanged.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+import sys
+import time
+from pathlib import Path
+from typing import List, Sequence
+
+import numpy as np
+
+from . import checkpoint, nifti, ops, predictor, preprocessing
+from .network import UNet
+
+#: the two ensemble members (reference :263-264)
+MODEL1 = "nnUNetTrainerV2BraTSRegions_DA4_BN_BD__nnUNetPlansv2.1"
+MODEL2 = "nnUNetTrainerV2BraTSRegions_DA4_BN_BD_largeUnet_Groupnorm__nnUNetPlansv2.1"
+MODALITY_MAP = {"t1": "0000", "t1ce": "0001", "t2": "0002", "flair": "0003"}  # reference :48-53
+
+
+def prepare_input(sample_dir, output_dir):
+    """Reference :26-78.  BraTS names -> nnU-Net names, copied into ``output_dir``; a case with a
+    missing modality is skipped with a warning.  Returns [(case, [4 paths in channel order])].
+    (Cases are returned sorted; the reference iterates a Python set, i.e. in arbitrary order.)"""
+    sample_dir, output_dir = Path(sample_dir), Path(output_dir)
+    output_dir.mkdir(parents=True, exist_ok=True)
+    cases = set()
+    for file in sample_dir.glob("*.nii.gz"):
+        parts = file.stem.replace(".nii", "").split("_")
+        if parts[-1] in ["t1", "t1ce", "t2", "flair", "seg"]:
+            cases.add("_".join(parts[:-1]))
+    print(f"Found {len(cases)} cases: {cases}")
+    prepared = []
+    for case in sorted(cases):
+        files, ok = [], True
+        for mod, idx in MODALITY_MAP.items():
+            src = sample_dir / f"{case}_{mod}.nii.gz"
+            dst = output_dir / f"{case}_{idx}.nii.gz"
+            if src.exists():
+                if not dst.exists():
+                    shutil.copy(src, dst)
+                files.append(str(dst))
+            else:
+                print(f"[WARNING] Missing {mod} for {case}")
+                ok = False
+                break
+        if ok:
+            prepared.append((case, files))
+    return prepared
+
+
+class LoadedModel:
+    """trainer + params of the reference (:178-183): one device network per fold."""
+
+    def __init__(self, folder: checkpoint.ModelFolder, dtype: str = "f32"):
+        self.folder = folder
+        self.nets: List[UNet] = [UNet(sd, norm=folder.norm, num_groups=folder.num_groups, dtype=dtype)
+                                 for sd in folder.fold_state_dicts]
+        self.patch_size = folder.patch_size
+        self.nonlin = "sigmoid" if folder.regions else "softmax"
+
+    def close(self):
+        for n in self.nets:
+            n.close()
+
+
+def read_case(list_of_files: Sequence[str]):
+    """The four modality files -> float32 [4, Z, Y, X] (SimpleITK axis order) + the first image (geometry)."""
+    imgs = [nifti.load(f) for f in list_of_files]
+    shapes = {im.data.shape for im in imgs}
+    if len(shapes) != 1:
+        raise ValueError(f"modalities have different shapes: {shapes}")
+    return np.stack([im.as_zyx().astype(np.float32) for im in imgs]), imgs[0]
+
+
+def predict_case_single_threaded(model: LoadedModel, list_of_files, output_file, do_tta=True, mixed_precision=True,
+                                 step_size=0.5, all_in_gpu=True, save_npz=False, timings=None):
+    """Reference :81-158: preprocess once, predict with every fold, average, export with
+    region_class_order=(1,2,3).  Returns (output_file, mean probabilities on the device)."""
+    import torch
+    t0 = time.perf_counter()
+    print(f"Preprocessing {output_file}")
+    raw, like = read_case(list_of_files)
+    data, props = preprocessing.preprocess_case(raw)
+    print(f"Data shape after preprocessing: {tuple(data.shape)}")
+    print(f"Predicting {output_file}")
+    t1 = time.perf_counter()
+    probs = predictor.predict_folds(model.nets, data, model.patch_size, step_size, do_tta, (0, 1, 2), True,
+                                    model.nonlin)
+    print(f"Ensembling {len(model.nets)} folds")
+    lo = [b[0] for b in props["crop_bbox"]]
+    if model.folder.regions:
+        seg = ops.regions_to_labels(probs, (1, 2, 3), lo, props["original_size_of_raw_data"])
+    else:
+        seg = torch.zeros(props["original_size_of_raw_data"], dtype=torch.uint8, device=probs.device)
+        sz = probs.shape[1:]
+        seg[lo[0]:lo[0] + sz[0], lo[1]:lo[1] + sz[1], lo[2]:lo[2] + sz[2]] = probs.argmax(0).to(torch.uint8)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"Saving segmentation to {output_file}")
+    seg_zyx = seg.cpu().numpy()
+    nifti.save_like(output_file, np.ascontiguousarray(seg_zyx.transpose(2, 1, 0)), like)
+    if save_npz:
+        np.savez_compressed(str(output_file).replace(".nii.gz", ".npz"), softmax=probs.cpu().numpy(),
+                            crop_bbox=np.array(props["crop_bbox"]))
+    if timings is not None:
+        timings.append(dict(read_preprocess_s=t1 - t0, predict_s=t2 - t1, export_s=time.perf_counter() - t2))
+    return output_file, probs, props
+
+
+def run_model_single_threaded(model_folder, input_folder, output_folder, folds=(0, 1, 2, 3, 4), do_tta=True,
+                              step_size=0.5, save_npz=False, dtype="f32"):
+    """Reference :161-214."""
+    model_folder, input_folder, output_folder = Path(model_folder), Path(input_folder), Path(output_folder)
+    if not model_folder.exists():
+        print(f"[ERROR] Model not found: {model_folder}")
+        sys.exit(1)
+    print(f"Model path: {model_folder}")
+    print(f"Loading model with folds: {folds}")
+    model = LoadedModel(checkpoint.load_model_folder(model_folder, folds, "model_final_checkpoint"), dtype=dtype)
+    print(f"Loaded {len(model.nets)} fold checkpoints")
+    prepared = prepare_input(input_folder, output_folder / "temp_input")
+    if not prepared:
+        print("[ERROR] No valid cases found!")
+        model.close()
+        return []
+    outputs = []
+    for case_name, case_files in prepared:
+        output_file = output_folder / f"{case_name}.nii.gz"
+        output_folder.mkdir(parents=True, exist_ok=True)
+        print(f"\n{'=' * 70}\nProcessing case: {case_name}\n{'=' * 70}")
+        timings = []
+        predict_case_single_threaded(model, case_files, str(output_file), do_tta=do_tta, step_size=step_size,
+                                     save_npz=save_npz, timings=timings)
+        t = timings[0]
+        print(f"[OK] Completed: {output_file}  (read+preprocess {t['read_preprocess_s']:.2f} s, "
+              f"predict {t['predict_s']:.2f} s, export {t['export_s']:.2f} s)")
+        outputs.append(output_file)
+    model.close()
+    return outputs
+
+
+def calculate_volumes(seg_path):
+    """Reference :217-243 - including its use of BraTS label 4 for ET on a file that holds
+    nnU-Net label 3 (so ET prints 0.00 before convert_labels_to_brats.py has run)."""
+    img = nifti.load(seg_path)
+    seg = img.data
+    voxel_volume_cm3 = float(np.prod(img.zooms)) / 1000.0
+    ncr, ed, et = int(np.sum(seg == 1)), int(np.sum(seg == 2)), int(np.sum(seg == 4))
+    return {"NCR": ncr * voxel_volume_cm3, "ED": ed * voxel_volume_cm3, "ET": et * voxel_volume_cm3,
+            "TC": (ncr + et) * voxel_volume_cm3, "WT": (ncr + ed + et) * voxel_volume_cm3}
+
+
+def ensemble_label_files(model1_output: Path, model2_output: Path, output_folder: Path):
+    """Reference :286-322: np.round((seg1 + seg2) / 2) per voxel, saved with seg1's header."""
+    import torch
+    finals = []
+    for seg1_path in sorted(model1_output.glob("*.nii.gz")):
+        case_name = seg1_path.stem.replace(".nii", "")
+        seg2_path = model2_output / seg1_path.name
+        if not seg2_path.exists():
+            print(f"[WARNING] Missing model2 prediction for {case_name}")
+            continue
+        print(f"Ensembling {case_name}")
+        img1, img2 = nifti.load(seg1_path), nifti.load(seg2_path)
+        a = torch.from_numpy(np.ascontiguousarray(img1.data.astype(np.uint8))).cuda()
+        b = torch.from_numpy(np.ascontiguousarray(img2.data.astype(np.uint8))).cuda()
+        ens = ops.label_ensemble(a, b).cpu().numpy()
+        final_output = output_folder / f"{case_name}.nii.gz"
+        nifti.save_like(final_output, ens, img1)
+        print(f"[OK] Saved: {final_output}")
+        v = calculate_volumes(final_output)
+        print(f"\nTumor Volume Analysis for {case_name}:")
+        print(f"  NCR (Necrotic Core):        {v['NCR']:.2f} cm3")
+        print(f"  ED (Peritumoral Edema):     {v['ED']:.2f} cm3")
+        print(f"  ET (Enhancing Tumor):       {v['ET']:.2f} cm3")
+        print(f"  TC (Tumor Core):            {v['TC']:.2f} cm3")
+        print(f"  WT (Whole Tumor):           {v['WT']:.2f} cm3")
+        finals.append(final_output)
+    return finals
+
+
+def main(argv=None, script_dir=None):
+    """Reference :246-327.  --input/--output are the whole contract; the extra flags default to the
+    reference's hard-coded settings (5 folds, TTA on, step 0.5)."""
+    ap = argparse.ArgumentParser(description="BraTS 2021 Brain Tumor Segmentation (MI355X-native)")
+    ap.add_argument("--input", type=str, required=True, help="Input directory with BraTS sample data")
+    ap.add_argument("--output", type=str, required=True, help="Output directory for segmentation results")
+    ap.add_argument("--results_folder", type=str, default=None, help="default: <script dir>/nnUNet_results")
+    ap.add_argument("--folds", type=int, nargs="+", default=[0, 1, 2, 3, 4])
+    ap.add_argument("--disable_tta", action="store_true")
+    ap.add_argument("--step_size", type=float, default=0.5)
+    args = ap.parse_args(argv)
+    script_dir = Path(script_dir) if script_dir else Path(__file__).resolve().parent.parent
+    results_folder = Path(args.results_folder or os.environ.get("MI355_RESULTS_FOLDER") or script_dir / "nnUNet_results")
+    os.environ["RESULTS_FOLDER"] = str(results_folder)
+    print("=" * 70 + "\nBraTS 2021 TUMOR SEGMENTATION (MI355X-native HIP path)\n" + "=" * 70)
+    print(f"RESULTS_FOLDER: {results_folder}\n")
+    base = results_folder / "3d_fullres" / "Task500_BraTS2021"
+    output_folder = Path(args.output)
+    outs = []
+    for i, name in enumerate((MODEL1, MODEL2), 1):
+        print("\n" + "=" * 70 + f"\nMODEL {i}: {name.split('__')[0]}\n" + "=" * 70)
+        outs.append(output_folder / f"temp_model{i}")
+        run_model_single_threaded(base / name, args.input, outs[-1], tuple(args.folds), not args.disable_tta,
+                                  args.step_size)
+    print("\n" + "=" * 70 + "\nENSEMBLING MODEL PREDICTIONS\n" + "=" * 70)
+    ensemble_label_files(outs[0], outs[1], output_folder)
+    print("\n" + "=" * 70 + "\nSEGMENTATION COMPLETE!\n" + "=" * 70)
+    print(f"Results saved to: {output_folder}")
+    return 0

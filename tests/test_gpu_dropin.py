@@ -1,0 +1,73 @@
+"""-m gpu: the drop-in boundary end to end - the repo-root ``run_brats2021_inference_singlethread.py``
+invoked exactly as run_full_pipeline.py:162-182 does (subprocess, --input/--output), on a synthetic
+BraTS-named case with synthetic two-model / multi-fold checkpoints, compared with the oracle's
+restatement of the whole driver (preprocess -> folds -> mean -> regions -> label-round ensemble)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import driver_ref, tiler_ref, unet_ref
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_case(amd, folder, case, shape_zyx, seed):
+    vol = amd.synthetic.make_volume(seed=seed, shape=shape_zyx)
+    like = amd.nifti.make_header(shape_zyx[::-1], zooms=(1.0, 1.0, 1.0), origin=(0.0, -239.0, 0.0))
+    for c, mod in enumerate(("t1", "t1ce", "t2", "flair")):
+        amd.nifti.save_like(folder / f"{case}_{mod}.nii.gz", np.ascontiguousarray(np.round(vol[c]).astype(np.int16).transpose(2, 1, 0)), like)
+    raw = np.stack([amd.nifti.load(folder / f"{case}_{m}.nii.gz").as_zyx().astype(np.float32) for m in ("t1", "t1ce", "t2", "flair")])
+    return raw
+
+
+def test_dropin_script_matches_oracle_driver(amd, gpu, tmp_path):
+    patch = (32, 32, 32)
+    results = tmp_path / "nnUNet_results"
+    base = results / "3d_fullres" / "Task500_BraTS2021"
+    plans = amd.checkpoint.default_brats_plans(patch)
+    sds1 = [amd.synthetic.make_model("A", seed=40 + k, num_pool=2, max_feat=128)[0] for k in range(2)]
+    sds2 = [amd.synthetic.make_model("B", seed=50 + k, num_pool=2, max_feat=128)[0] for k in range(2)]
+    amd.checkpoint.save_model_folder(base / amd.driver.MODEL1, amd.driver.MODEL1.split("__")[0], sds1, plans)
+    amd.checkpoint.save_model_folder(base / amd.driver.MODEL2, amd.driver.MODEL2.split("__")[0], sds2, plans)
+    case_dir = tmp_path / "BraTS-GLI-00003-000"
+    case_dir.mkdir()
+    raw = _write_case(amd, case_dir, "BraTS-GLI-00003-000", (40, 56, 48), seed=77)
+    out = tmp_path / "results" / "BraTS-GLI-00003-000"
+    env = dict(os.environ, nnUNet_raw_data_base="x", nnUNet_preprocessed="y", RESULTS_FOLDER="z")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "run_brats2021_inference_singlethread.py"),
+                          "--input", str(case_dir), "--output", str(out), "--results_folder", str(results),
+                          "--folds", "0", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    final = out / "BraTS-GLI-00003-000.nii.gz"
+    assert final.exists()                                              # run_full_pipeline.py:191-193
+    for k in (1, 2):
+        assert (out / f"temp_model{k}" / "BraTS-GLI-00003-000.nii.gz").exists()
+        assert (out / f"temp_model{k}" / "temp_input" / "BraTS-GLI-00003-000_0003.nii.gz").exists()
+    img = amd.nifti.load(final)
+    like = amd.nifti.load(case_dir / "BraTS-GLI-00003-000_t1.nii.gz")
+    assert img.data.dtype == np.uint8 and img.data.shape == like.data.shape and img.zooms == like.zooms
+    assert np.allclose(img.affine, like.affine) and set(np.unique(img.data)) <= {0, 1, 2, 3}
+    # oracle restatement of the whole driver
+    seg1, p1, _ = driver_ref.predict_case(raw, sds1, unet_ref.default_cfg("batch"), patch)
+    seg2, p2, _ = driver_ref.predict_case(raw, sds2, unet_ref.default_cfg("group", 16), patch)
+    want = driver_ref.label_ensemble(seg1, seg2)
+    got = img.as_zyx()
+    for k, ref in ((1, seg1), (2, seg2)):
+        part = amd.nifti.load(out / f"temp_model{k}" / "BraTS-GLI-00003-000.nii.gz").as_zyx()
+        assert tiler_ref.brats_region_dice(part, ref)["mean"] >= 0.999
+    d = tiler_ref.brats_region_dice(got, want)
+    assert d["mean"] >= 0.999, d
+    assert (got != want).mean() < 1e-4
+    assert "Tumor Volume Analysis" in res.stdout and "SEGMENTATION COMPLETE" in res.stdout
+
+
+def test_dropin_missing_models_exit_code(amd, gpu, tmp_path):
+    (tmp_path / "in").mkdir()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "run_brats2021_inference_singlethread.py"),
+                          "--input", str(tmp_path / "in"), "--output", str(tmp_path / "out"),
+                          "--results_folder", str(tmp_path / "none")], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 1 and "[ERROR] Model not found" in res.stdout
