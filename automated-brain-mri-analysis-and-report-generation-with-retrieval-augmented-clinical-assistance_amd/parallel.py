@@ -1,0 +1,85 @@
+"""Multi-GPU sharding of the path: one process per GPU, torch.distributed over RCCL/xGMI
+(backend "nccl" on ROCm; "gloo" in the CPU tests).  SURVEY.md 8e.
+
+* Partitioning A (throughput; BASELINE.json configs[3], bench.py): CASES are dealt round-robin to
+  ranks, every rank holds the weights, no data-path collective; an optional all_gather of the
+  uint8 label maps (8.9 MB each) brings results to every rank.
+* Partitioning B (latency of ONE case): the tile list is dealt round-robin
+  (``mi355_sw_partial``), each rank holds a Gaussian-weighted partial aggregate, and there is one
+  exchange step: an all_gather of the partial aggregates (3 x Zp x Yp x Xp fp32, about 40 MB per
+  rank) followed by a sum in RANK ORDER on every rank, so all ranks obtain bit-identical
+  probabilities (a ring all-reduce would add in a topology-dependent order).
+"""
+from __future__ import annotations
+
+import os
+from typing import List
+
+
+def init_distributed(backend: str = None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torch.distributed.run)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, **kw)
+    return rank, world, local_rank
+
+
+def shard_cases(n_cases: int, rank: int, world: int) -> List[int]:
+    """Round-robin: case i goes to rank i % world."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return list(range(rank, n_cases, world))
+
+
+def shard_tiles(n_tiles: int, rank: int, world: int) -> List[int]:
+    """The tile assignment ``mi355_sw_partial`` uses (tile index % world == rank)."""
+    return list(range(rank, n_tiles, world))
+
+
+def sum_partials_in_rank_order(partial, group=None):
+    """all_gather the per-rank partial aggregates, then add them 0,1,2,... on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return partial
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(partial) for _ in range(world)]
+    dist.all_gather(parts, partial.contiguous(), group=group)
+    total = parts[0].clone()
+    for r in range(1, world):
+        total += parts[r]
+    return total
+
+
+def gather_label_maps(seg, group=None):
+    """all_gather of equally-shaped uint8 label maps -> list indexed by rank."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [seg]
+    out = [torch.empty_like(seg) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, seg.contiguous(), group=group)
+    return out
+
+
+def predict_case_tile_sharded(net, data, patch_size=(128, 128, 128), step_size=0.5, do_mirroring=True,
+                              mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid", group=None):
+    """Partitioning B end to end on the GPU ranks of ``group``: identical probabilities on every rank."""
+    import torch.distributed as dist
+    from . import predictor
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    agg, cnt = predictor.predict_tile_sharded(net, data, rank, world, patch_size, step_size, do_mirroring,
+                                              mirror_axes, use_gaussian, nonlin)
+    agg = sum_partials_in_rank_order(agg, group)
+    return predictor.finish_sharded(agg, cnt, tuple(data.shape[1:]), patch_size)

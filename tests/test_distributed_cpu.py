@@ -1,0 +1,92 @@
+"""not gpu: the N > 1 orchestration with world_size 2 on the gloo backend.
+
+The compute stays on the GPU in the product; here each rank produces its tile-sharded partial
+aggregate with the ORACLE (same tile assignment as mi355_sw_partial: index % world == rank) and
+the product's exchange step (parallel.sum_partials_in_rank_order / gather_label_maps / shard_*)
+runs for real across two processes."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _partial_oracle(sd, vol, patch, rank, world):
+    from oracle import tiler_ref, unet_ref
+    net_fn = tiler_ref.make_net_fn(sd, unet_ref.default_cfg("batch"))
+    padded, lo = tiler_ref.pad_to_patch(vol, patch)
+    steps = tiler_ref.compute_steps_for_sliding_window(patch, padded.shape[1:], 0.5)
+    g = tiler_ref.get_gaussian(patch)
+    agg = np.zeros((3,) + padded.shape[1:], np.float32)
+    cnt = np.zeros(padded.shape[1:], np.float32)
+    idx = 0
+    for x in steps[0]:
+        for y in steps[1]:
+            for z in steps[2]:
+                sl = (slice(x, x + patch[0]), slice(y, y + patch[1]), slice(z, z + patch[2]))
+                cnt[sl] += g
+                if idx % world == rank:
+                    t = torch.from_numpy(np.ascontiguousarray(padded[(slice(None),) + sl][None]))
+                    pred = tiler_ref.mirror_and_predict(net_fn, t, (0, 1, 2), False, "sigmoid", torch.from_numpy(g))[0].numpy()
+                    agg[(slice(None),) + sl] += pred
+                idx += 1
+    return agg, cnt, idx
+
+
+def _worker(rank, world, port, tmp):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import brats_amd
+    from oracle import tiler_ref, unet_ref
+    r, w, _ = brats_amd.parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    sd, _ = brats_amd.synthetic.make_model("A", seed=21, num_pool=2, max_feat=64)
+    vol = np.random.RandomState(8).standard_normal((4, 24, 40, 20)).astype(np.float32)
+    patch = (16, 16, 16)
+    agg, cnt, n_tiles = _partial_oracle(sd, vol, patch, rank, world)
+    assert brats_amd.parallel.shard_tiles(n_tiles, rank, world) == list(range(rank, n_tiles, world))
+    total = brats_amd.parallel.sum_partials_in_rank_order(torch.from_numpy(agg))
+    probs = (total.numpy() / cnt[None])
+    full = tiler_ref.predict_3d_tiled(tiler_ref.make_net_fn(sd, unet_ref.default_cfg("batch")), vol, patch, 3, 0.5,
+                                      False, (0, 1, 2), True, "sigmoid")
+    lo = [(max(p, s) - s) // 2 for p, s in zip(patch, vol.shape[1:])]
+    probs = probs[:, lo[0]:lo[0] + 24, lo[1]:lo[1] + 40, lo[2]:lo[2] + 20]
+    assert np.abs(probs - full).max() < 1e-5
+    # bit-identical on every rank (rank-ordered sum), and label maps gather by rank
+    gathered = [torch.empty_like(total) for _ in range(world)]
+    dist.all_gather(gathered, total)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    seg = torch.full((3, 4), rank, dtype=torch.uint8)
+    maps = brats_amd.parallel.gather_label_maps(seg)
+    assert [int(m[0, 0]) for m in maps] == list(range(world))
+    assert brats_amd.parallel.shard_cases(5, rank, world) == list(range(rank, 5, world))
+    np.save(os.path.join(tmp, f"ok_{rank}.npy"), np.array([1]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_tile_sharding(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"ok_{r}.npy").exists() for r in range(2))
+
+
+def test_shard_helpers(amd):
+    assert amd.parallel.shard_cases(32, 3, 8) == [3, 11, 19, 27]
+    assert sorted(sum((amd.parallel.shard_cases(10, r, 4) for r in range(4)), [])) == list(range(10))
+    with pytest.raises(ValueError):
+        amd.parallel.shard_cases(4, 4, 4)
