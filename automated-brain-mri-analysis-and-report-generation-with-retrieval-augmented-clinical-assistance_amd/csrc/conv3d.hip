@@ -40,6 +40,71 @@ struct ConvArgs {
     float slope;
 };
 
+// Shared epilogue.  The MFMAs are issued as D = W x X (weights are the A operand, voxels the B operand),
+// so a lane holds ONE voxel (column lane&31) and, in its 16 accumulator registers, 16 couts:
+// cout = (r&3) + 8*(r>>2) + 4*(lane>>5).  Registers 4g..4g+3 are four consecutive couts -> one 16-B store;
+// 4 stores per 32x32 tile instead of 16 dword stores (the store tail is issue-bound, not bandwidth-bound).
+// Adds bias, optional LeakyReLU, predicated on the volume bounds; optional per-(n, cout) sum / sum of squares:
+// butterfly over the 32 voxel lanes, then LDS across the 4 waves, then one fp64 atomic per cout.
+template <int MF, int NF>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvArgs &p, int n, int oz0, int oy0,
+                                              int ox0, int co_blk, float *red, bool sync_before_red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
+    float s1[NF][16], s2[NF][16];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[nf][r] = 0.f; s2[nf][r] = 0.f; }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int v = (wave * MF + mf) * 32 + l31;
+        const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
+        const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
+        float *orow = p.out + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + 4 * half;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bias = *(const f32x4 *)(p.bias + co_blk + nf * 32 + 8 * g + 4 * half);
+                f32x4 val;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float x = acc[mf][nf][4 * g + k] + bias[k];
+                    if (p.act == ACT_LRELU) x = x > 0.f ? x : x * p.slope;
+                    val[k] = x;
+                    if (ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
+                }
+                if (ok) *(f32x4 *)(orow + nf * 32 + 8 * g) = val;
+            }
+        }
+    }
+    if (p.stats) {
+        if (sync_before_red) __syncthreads();
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = s1[nf][r], b = s2[nf][r];
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+                if (l31 == 0) {
+                    const int c = nf * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    red[(wave * NF * 32 + c) * 2 + 0] = a;
+                    red[(wave * NF * 32 + c) * 2 + 1] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < NF * 32 * 2) {
+            const int c = tid >> 1, k = tid & 1;
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
+            atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, tot);
+        }
+    }
+}
+
 template <int STRIDE, int CC, int MF, int NF>
 __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -158,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
                     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
                         for (int nf = 0; nf < NF; ++nf)
-                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mf][j], b_cur[nf][j],
+                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nf][j], a_cur[mf][j],
                                                                                acc[mf][nf], 0, 0, 0);
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf)
@@ -171,60 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
         __syncthreads();  // brick is overwritten by the next chunk
     }
 
-    // ---- epilogue.  C/D map of 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float s1[NF], s2[NF];
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-        s1[nf] = 0.f; s2[nf] = 0.f;
-    }
-    const int co_blk = (int)blockIdx.y * NF * 32;
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int v = (wave * MF + mf) * 32 + row;
-            const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
-            const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
-            float *orow = p.out + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + l31;
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) {
-                float val = acc[mf][nf][r] + (p.bias ? p.bias[co_blk + nf * 32 + l31] : 0.f);
-                if (p.act == ACT_LRELU)
-                    val = val > 0.f ? val : val * p.slope;
-                if (ok) {
-                    orow[nf * 32] = val;
-                    s1[nf] += val;
-                    s2[nf] += val * val;
-                }
-            }
-        }
-    }
-    if (p.stats) {
-        // lanes l and l+32 hold the same channel
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-            s1[nf] += __shfl_xor(s1[nf], 32);
-            s2[nf] += __shfl_xor(s2[nf], 32);
-        }
-        float *red = lds;  // [4 waves][NF*32][2]; the brick is dead (barrier above)
-        if (half == 0) {
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) {
-                red[(wave * NF * 32 + nf * 32 + l31) * 2 + 0] = s1[nf];
-                red[(wave * NF * 32 + nf * 32 + l31) * 2 + 1] = s2[nf];
-            }
-        }
-        __syncthreads();
-        if (tid < NF * 32 * 2) {
-            const int c = tid >> 1, k = tid & 1;
-            double tot = 0.0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-                tot += (double)red[(w * NF * 32 + c) * 2 + k];
-            atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, tot);
-        }
-    }
+    conv_epilogue<MF, NF>(acc, p, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32, lds, /*sync_before_red=*/false);
 }
 
 // ------------------------------------------------------------------ direct kernel (any shape)

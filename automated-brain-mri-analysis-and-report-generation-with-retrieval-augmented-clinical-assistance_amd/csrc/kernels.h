@@ -14,6 +14,7 @@ struct ConvWeights {
     int cin = 0, cin_pad = 0, cout = 0, stride = 1;
     int cc = 0;               // channel chunk staged in LDS per pass
     int nf = 1;               // 32-wide cout fragments per workgroup
+    bool pipe = false;        // pipelined (persistent, double-buffered) kernel; implies cc == 8
     float *wp_dev = nullptr;  // packed weights (device)
     float *bias_dev = nullptr;
     float *w_plain_dev = nullptr;  // [cout][cin][27] PyTorch order (direct kernel / tests)
