@@ -19,6 +19,7 @@
 // (wave reduction -> LDS -> one fp64 atomic per channel per workgroup).
 #include "kernels.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -239,6 +240,197 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
     conv_epilogue<MF, NF>(acc, p, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32, lds, /*sync_before_red=*/false);
 }
 
+
+// ------------------------------------------------------------------ pipelined variant (stride 1)
+// Same GEMM mapping, restructured so the matrix pipe never waits for staging (tools/conv_probe2.hip is the
+// micro-benchmark this structure was developed on: +20 % over the kernel above on the 32->32 layer shape):
+//   * persistent workgroups walk a contiguous, XCD-local range of output tiles;
+//   * the input brick is staged in 8-channel chunks into a DOUBLE-buffered LDS image while the 27 tap steps of
+//     the previous chunk run: slot r (one 16-B piece per thread) is fetched at step 2r - after that step's
+//     weight fetch, so it is the youngest entry of the in-order vmcnt queue - and written to the other buffer
+//     five steps later.  Every staging load is unconditional (out-of-volume / unused slots read the tensor
+//     base and are zeroed or dropped at the write), so the compiler's vmcnt counts are static;
+//   * LDS image is planar [16-B channel quad][brick voxel]: x-consecutive lanes read consecutive 16-B slots
+//     (conflict-free ds_read_b128, no padding);
+//   * weight fragments come through a 3-deep register ring (fetched 3 steps ahead), voxel fragments are
+//     double-registered (no copies); MF = 4 voxel fragments per wave when Cout = 32 halves the number of
+//     weight fetches per MFMA;
+//   * one barrier per chunk; 2 workgroups per CU.
+struct PipeArgs {
+    ConvArgs c;
+    int total_tiles;   // N * tiles per sample
+    int plane;         // floats per LDS plane (= brickvox * 4)
+    int buf_floats;    // floats per LDS buffer (= 2 * plane)
+};
+
+template <int MF, int NF>
+__global__ __launch_bounds__(256, 2) void conv3_f32_mfma_pipe_kernel(PipeArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvArgs &p = pa.c;
+    constexpr int CC = 8;
+    constexpr int SLOTS = MF == 4 ? 11 : 8;  // 16-B staging pieces per thread and chunk (brick <= SLOTS*128 voxels)
+    constexpr int BD = 3;                    // weight fragments are fetched BD tap-steps ahead
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
+    const int IX = p.IX, IY = p.IY;
+    const int brickvox = IX * IY * p.IZ;
+    const int npieces = 2 * brickvox;
+    float *red = lds + 2 * pa.buf_floats;  // [4 waves][NF*32][2] stats scratch, never aliased with a brick
+
+    // this workgroup's tile sequence: XCD group x owns the contiguous range [lo, hi); its workgroups stride through it
+    const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x - xcd + 7) >> 3;
+    const int q8 = pa.total_tiles >> 3, r8 = pa.total_tiles & 7;
+    const int lo = xcd * q8 + (xcd < r8 ? xcd : r8);
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + li;
+    if (tile >= hi) return;
+
+    // per-lane LDS offsets (floats) of each voxel fragment at tap (0,0,0), in plane `half`
+    int a_base[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int v = (wave * MF + mf) * 32 + l31;
+        const int x = v & TXm, y = (v >> p.lx) & TYm, z = v >> (p.lx + p.ly);
+        a_base[mf] = half * pa.plane + ((z * IY + y) * IX + x) * 4;
+    }
+    const int qoff = (tid & 1) * 4;
+
+    struct TileCoord { int n, oz0, oy0, ox0; };
+    auto decode = [&](int t) {
+        TileCoord tc;
+        tc.n = (int)fdiv((uint32_t)t, p.div_tiles_per_n);
+        const int tt = t - tc.n * (int)p.div_tiles_per_n.d;
+        const int tzy = (int)fdiv((uint32_t)tt, p.div_tiles_x);
+        const int tile_x = tt - tzy * p.tiles_x;
+        const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
+        const int tile_y = tzy - tile_z * p.tiles_y;
+        tc.oz0 = tile_z << p.lz; tc.oy0 = tile_y << p.ly; tc.ox0 = tile_x << p.lx;
+        return tc;
+    };
+    // staging slot r = piece i = r*256 + tid = (brick voxel i>>1, quad i&1); lanes (2k, 2k+1) fetch the 32
+    // contiguous bytes of one voxel.  dst = LDS offset in floats or -1; inside = voxel lies in the volume.
+    auto stage_issue = [&](const TileCoord &tc, int ch, int r, int &dst, bool &inside) {
+        const int cglob = ch * CC;
+        const float *src; int Csrc, coff;
+        if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
+        else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
+        const int i = r * 256 + tid;
+        const int bv = i >> 1;
+        const int rr = (int)fdiv((uint32_t)bv, p.div_IX);
+        const int bx = bv - rr * IX;
+        const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
+        const int by = rr - bz * IY;
+        const int iz = tc.oz0 - 1 + bz, iy = tc.oy0 - 1 + by, ix = tc.ox0 - 1 + bx;
+        dst = (i < npieces) ? (i & 1) * pa.plane + bv * 4 : -1;
+        inside = (i < npieces) && ((unsigned)iz < (unsigned)p.Di) && ((unsigned)iy < (unsigned)p.Hi) &&
+                 ((unsigned)ix < (unsigned)p.Wi);
+        size_t off = ((((size_t)tc.n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * Csrc + coff + qoff;
+        off = inside ? off : 0;
+        return *(const f32x4 *)(src + off);
+    };
+
+    f32x16 acc[MF][NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[mf][nf][r] = 0.f;
+
+    const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 256) + lane * 4;
+    const int co_blk = (int)blockIdx.y * NF * 32;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // prologue: stage (tile, chunk 0) into buffer 0; first BD weight fragments
+    TileCoord cur = decode(tile);
+#pragma unroll
+    for (int r = 0; r < SLOTS; ++r) {
+        bool inside; int dst;
+        const f32x4 v = stage_issue(cur, 0, r, dst, inside);
+        if (dst >= 0) *(f32x4 *)(lds + dst) = inside ? v : zero4;
+    }
+    f32x4 bq[BD][NF];
+#pragma unroll
+    for (int k = 0; k < BD; ++k)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) bq[k][nf] = *(const f32x4 *)(wblk + (size_t)k * (NF * 256) + nf * 256);
+    __syncthreads();
+
+    int ch = 0, buf = 0;
+    while (true) {
+        // what comes after (tile, ch)
+        int ntile = tile, nch = ch + 1;
+        if (nch == p.nchunks) { nch = 0; ntile = tile + nl; }
+        const bool have_next = ntile < hi;
+        const TileCoord nxt = (nch == 0 && have_next) ? decode(ntile) : cur;
+        const int nch_eff = have_next ? nch : ch;  // last chunk of this workgroup: harmless re-read
+        const float *bufc = lds + buf * pa.buf_floats;
+        float *bufn = lds + (buf ^ 1) * pa.buf_floats;
+        const float *wch = wblk + (size_t)ch * (27 * NF * 256);
+        const float *wnx = wblk + (size_t)nch_eff * (27 * NF * 256);
+
+        f32x4 a[2][MF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) a[0][mf] = *(const f32x4 *)(bufc + a_base[mf]);
+        f32x4 st_v[SLOTS];
+        int st_dst[SLOTS];
+        bool st_in[SLOTS];
+
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) {
+                const int nt = tap + 1;
+                const int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
+                const int off = ((dz * IY + dy) * IX + dx) * 4;
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) a[(tap + 1) & 1][mf] = *(const f32x4 *)(bufc + a_base[mf] + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf)
+                        acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[tap % BD][nf][j], a[tap & 1][mf][j], acc[mf][nf], 0, 0, 0);
+            {   // refill this ring slot with the fragment BD steps ahead (possibly of the next chunk)
+                const int k = tap + BD;
+                const float *wsrc = (k < 27) ? wch + (size_t)k * (NF * 256) : wnx + (size_t)(k - 27) * (NF * 256);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) bq[tap % BD][nf] = *(const f32x4 *)(wsrc + nf * 256);
+            }
+            if ((tap & 1) == 0 && tap / 2 < SLOTS) {
+                const int r = tap / 2;
+                st_v[r] = stage_issue(nxt, nch_eff, r, st_dst[r], st_in[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < SLOTS; ++r) {
+                const int wr = 2 * r + 5 < 26 ? 2 * r + 5 : 26;   // write step of slot r
+                if (wr == tap && have_next && st_dst[r] >= 0) *(f32x4 *)(bufn + st_dst[r]) = st_in[r] ? st_v[r] : zero4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // next brick complete and visible; this brick free for the chunk after next
+
+        if (ch == p.nchunks - 1) {
+            conv_epilogue<MF, NF>(acc, p, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red, /*sync_before_red=*/false);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+        }
+        if (!have_next) break;
+        tile = ntile; ch = nch; cur = nxt; buf ^= 1;
+    }
+}
+
 // ------------------------------------------------------------------ direct kernel (any shape)
 // One thread per (voxel, cout); used for shapes the MFMA path does not cover and as an
 // independent on-device cross-check of it in the parity tests.
@@ -287,6 +479,15 @@ __global__ void conv3_direct_kernel(const float *in0, const float *in1, int C0, 
 }
 
 // ------------------------------------------------------------------ host side
+static int g_conv_impl = -1;  // from env MI355_CONV_IMPL: "0" = one tile per workgroup kernel, default = pipelined
+static bool use_pipe() {
+    if (g_conv_impl < 0) {
+        const char *e = getenv("MI355_CONV_IMPL");
+        g_conv_impl = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_conv_impl == 1;
+}
+
 // Packed layout (floats): [cout_block][chunk][tap][g][nf][lane 0..63][j 0..3] with
 //   cout = (cout_block*NF + nf)*32 + (lane&31),  cin = chunk*CC + g*8 + (lane>>5)*4 + j.
 static void pack_conv_weights_f32(const float *w, int cin, int cin_pad, int cout, int cc, int nf,
@@ -316,7 +517,8 @@ int conv_weights_upload(const float *w_host, const float *bias_host, int cin, in
     const bool mfma_ok = (cout % 32 == 0) && (cin_pad % 8 == 0);
     if (mfma_ok) {
         // stride 2 bricks are ~8x the output tile: keep them to 8 channels per pass
-        cw.cc = (stride == 1 && cin_pad % 16 == 0) ? 16 : 8;
+        cw.pipe = (stride == 1) && use_pipe();
+        cw.cc = (!cw.pipe && stride == 1 && cin_pad % 16 == 0) ? 16 : 8;
         cw.nf = (cout % 64 == 0) ? 2 : 1;
         std::vector<float> packed;
         pack_conv_weights_f32(w_host, cin, cin_pad, cout, cw.cc, cw.nf, packed);
@@ -386,6 +588,31 @@ static int launch_conv(const ConvArgs &a, dim3 grid, size_t lds_bytes, hipStream
     return MI355_OK;
 }
 
+template <int MF, int NF>
+static int launch_pipe(const PipeArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s) {
+    auto kern = conv3_f32_mfma_pipe_kernel<MF, NF>;
+    static size_t attr_bytes = 48 * 1024;
+    if (lds_bytes > attr_bytes) {
+        MI355_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_bytes = lds_bytes;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, a);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+static void fill_geometry(ConvArgs &a, int st, int voxels) {
+    choose_tile(a.Do, a.Ho, a.Wo, st, voxels, &a.lz, &a.ly, &a.lx);
+    const int TX = 1 << a.lx, TY = 1 << a.ly, TZ = 1 << a.lz;
+    a.tiles_x = ceil_div(a.Wo, TX); a.tiles_y = ceil_div(a.Ho, TY); a.tiles_z = ceil_div(a.Do, TZ);
+    a.IX = (TX - 1) * st + 3; a.IY = (TY - 1) * st + 3; a.IZ = (TZ - 1) * st + 3;
+    a.div_tiles_per_n = make_fastdiv(a.tiles_x * a.tiles_y * a.tiles_z);
+    a.div_tiles_x = make_fastdiv(a.tiles_x);
+    a.div_tiles_y = make_fastdiv(a.tiles_y);
+    a.div_IX = make_fastdiv(a.IX);
+    a.div_IY = make_fastdiv(a.IY);
+}
+
 int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s) {
     MI355_REQUIRE(w.wp_dev != nullptr, "conv %d->%d has no MFMA weight pack", w.cin, w.cout);
     MI355_REQUIRE(c.C0 + c.C1 == w.cin_pad, "conv input channels %d+%d != %d", c.C0, c.C1, w.cin_pad);
@@ -398,23 +625,46 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s) {
     const int st = w.stride;
     a.Do = (c.Di - 1) / st + 1; a.Ho = (c.Hi - 1) / st + 1; a.Wo = (c.Wi - 1) / st + 1;  // k=3, p=1
     a.Cout = w.cout;
-    const int MF = (st == 1) ? 2 : 1;
-    choose_tile(a.Do, a.Ho, a.Wo, st, 128 * MF, &a.lz, &a.ly, &a.lx);
-    const int TX = 1 << a.lx, TY = 1 << a.ly, TZ = 1 << a.lz;
-    a.tiles_x = ceil_div(a.Wo, TX); a.tiles_y = ceil_div(a.Ho, TY); a.tiles_z = ceil_div(a.Do, TZ);
-    a.IX = (TX - 1) * st + 3; a.IY = (TY - 1) * st + 3; a.IZ = (TZ - 1) * st + 3;
-    const int tiles_per_n = a.tiles_x * a.tiles_y * a.tiles_z;
-    a.div_tiles_per_n = make_fastdiv(tiles_per_n);
-    a.div_tiles_x = make_fastdiv(a.tiles_x);
-    a.div_tiles_y = make_fastdiv(a.tiles_y);
-    a.div_IX = make_fastdiv(a.IX);
-    a.div_IY = make_fastdiv(a.IY);
     a.nchunks = w.cin_pad / w.cc;
     a.act = c.act; a.slope = c.slope;
-    const size_t brick_bytes = (size_t)a.IX * a.IY * a.IZ * (w.cc + 4) * sizeof(float);
+    if (w.pipe) {
+        const int gy = w.cout / (32 * w.nf);
+        // 4 voxel fragments per wave (512-voxel tiles) when that still gives every CU two workgroups
+        int MF = 4;
+        fill_geometry(a, 1, 128 * MF);
+        long tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * c.N;
+        if (tiles * gy < 512 || a.IX * a.IY * a.IZ > 11 * 128 || w.nf == 2) {
+            MF = 2;
+            fill_geometry(a, 1, 128 * MF);
+            tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * c.N;
+        }
+        MI355_REQUIRE(tiles < (1l << 30), "conv grid too large");
+        const int brickvox = a.IX * a.IY * a.IZ;
+        MI355_REQUIRE(brickvox <= (MF == 4 ? 11 : 8) * 128, "conv brick of %d voxels exceeds the staging slots", brickvox);
+        PipeArgs pa;
+        pa.c = a;
+        pa.total_tiles = (int)tiles;
+        pa.plane = brickvox * 4;
+        pa.buf_floats = 2 * pa.plane;
+        const size_t lds_bytes = (size_t)(2 * pa.buf_floats + 4 * w.nf * 32 * 2) * sizeof(float);
+        MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
+        int gx = 512 / gy;                      // ~2 resident workgroups per CU in total
+        gx = gx < 8 ? 8 : (gx / 8) * 8;         // multiple of 8: blockIdx.x & 7 labels the XCD group
+        const int need = (int)((tiles + 7) / 8) * 8;
+        if (gx > need) gx = need;
+        dim3 grid(gx, gy);
+        if (MF == 4) return launch_pipe<4, 1>(pa, grid, lds_bytes, s);
+        if (w.nf == 1) return launch_pipe<2, 1>(pa, grid, lds_bytes, s);
+        return launch_pipe<2, 2>(pa, grid, lds_bytes, s);
+    }
+    const int MF = (st == 1) ? 2 : 1;
+    fill_geometry(a, st, 128 * MF);
+    const int tiles_per_n = a.tiles_x * a.tiles_y * a.tiles_z;
+    MI355_REQUIRE((long)tiles_per_n * c.N < (1l << 30), "conv grid too large");
+    const int brickvox = a.IX * a.IY * a.IZ;
+    const size_t brick_bytes = (size_t)brickvox * (w.cc + 4) * sizeof(float);
     const size_t lds_bytes = brick_bytes < 4096 ? 4096 : brick_bytes;  // >= the stats scratch
     MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
-    MI355_REQUIRE((long)tiles_per_n * c.N < (1l << 30), "conv grid too large");
     dim3 grid(tiles_per_n * c.N, w.cout / (32 * w.nf));
     if (st == 1 && w.cc == 16 && w.nf == 1) return launch_conv<1, 16, 2, 1>(a, grid, lds_bytes, s);
     if (st == 1 && w.cc == 16 && w.nf == 2) return launch_conv<1, 16, 2, 2>(a, grid, lds_bytes, s);
