@@ -633,7 +633,7 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s) {
         int MF = 4;
         fill_geometry(a, 1, 128 * MF);
         long tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * c.N;
-        if (tiles * gy < 512 || a.IX * a.IY * a.IZ > 11 * 128 || w.nf == 2) {
+        if (tiles * gy < 512 || a.IX * a.IY * a.IZ > 11 * 128 || w.nf == 2) {  // (4,2) needs > 256 VGPRs
             MF = 2;
             fill_geometry(a, 1, 128 * MF);
             tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * c.N;

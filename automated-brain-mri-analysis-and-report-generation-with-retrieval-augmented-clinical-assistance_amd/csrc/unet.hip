@@ -211,7 +211,8 @@ struct ProfScope {
 static std::string conv_kernel_name(const ConvWeights &w) {
     if (!w.wp_dev) return "conv3_direct_kernel";
     char buf[64];
-    snprintf(buf, sizeof(buf), "conv3_f32_mfma_kernel<%d, %d, %d, %d>", w.stride, w.cc, w.stride == 1 ? 2 : 1, w.nf);
+    if (w.pipe) snprintf(buf, sizeof(buf), "conv3_f32_mfma_pipe_kernel<*, %d>", w.nf);  // MF (4|2) is chosen per launch
+    else snprintf(buf, sizeof(buf), "conv3_f32_mfma_kernel<%d, %d, %d, %d>", w.stride, w.cc, w.stride == 1 ? 2 : 1, w.nf);
     return buf;
 }
 
