@@ -24,7 +24,7 @@ EXPORTS = [
     "mi355_unet_flops", "mi355_unet_forward", "mi355_sw_predict", "mi355_compute_steps", "mi355_sw_partial",
     "mi355_sw_finish", "mi355_regions_to_labels", "mi355_label_ensemble", "mi355_prob_mean",
     "mi355_zscore_masked", "mi355_conv3d_ndhwc", "mi355_tconv3d_ndhwc", "mi355_profile_enable",
-    "mi355_profile_read",
+    "mi355_profile_read", "mi355_conv3d_ndhwc_f16", "mi355_tconv3d_ndhwc_f16",
 ]
 
 
@@ -100,6 +100,9 @@ def load():
     lib.mi355_conv3d_ndhwc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int,
                                        C.c_int, C.c_int, C.c_float, C.c_int, vp, vp]
     lib.mi355_tconv3d_ndhwc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, vp, vp]
+    lib.mi355_conv3d_ndhwc_f16.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int,
+                                           C.c_int, C.c_int, C.c_float, vp, vp]
+    lib.mi355_tconv3d_ndhwc_f16.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, vp, vp]
     lib.mi355_profile_enable.argtypes = [vp, C.c_int]
     lib.mi355_profile_read.argtypes = [vp, C.POINTER(ProfEntry), C.c_int]
     _lib = lib

@@ -1,0 +1,499 @@
+// 3x3x3 convolution, NDHWC fp16 storage / fp32 accumulate, on v_mfma_f32_32x32x16_f16 (gfx950).
+//
+// BASELINE.json configs[2] ("fp16") path of the same op as conv3d.hip (reference
+// model_architecture/generic_UNet.py:56,69 run under autocast upstream).  Same GEMM mapping as the
+// f32 kernels: D[cout][voxel] = W x X, weights are the MFMA A operand, voxels the B operand, so a lane
+// holds one voxel and 16 couts and the epilogue stores 4 consecutive couts (8 B) at a time.
+//   * one MFMA contracts a 16-channel chunk of one tap: lane l holds channels 8*(l>>5) .. +7 of
+//     cout / voxel l&31, i.e. ONE 16-byte read per fragment;
+//   * LDS image of the input brick is planar [8-channel half][brick voxel][16 B]: x-consecutive lanes
+//     read consecutive 16-B slots (conflict-free ds_read_b128), 32 B per voxel and chunk;
+//   * weights are packed on the host as [cout block][chunk][tap][nf][lane][8 halfs] (1 KiB fragments).
+// Two kernels: a simple one (one output tile per workgroup, stride 1|2) and the pipelined persistent
+// one for stride 1 (double-buffered brick staged while the 27 tap steps of the previous chunk run).
+#include "kernels.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace mi355 {
+
+typedef _Float16 half_t;
+
+struct ConvArgsH {
+    const half_t *in0, *in1;
+    const half_t *wp;
+    const float *bias;
+    half_t *out;
+    double *stats;
+    int C0, C1;
+    int N, Di, Hi, Wi, Do, Ho, Wo, Cout;
+    int lx, ly, lz;
+    int tiles_x, tiles_y, tiles_z;
+    int IX, IY, IZ;
+    FastDiv div_tiles_per_n, div_tiles_x, div_tiles_y, div_IX, div_IY;
+    int nchunks;
+    int act;
+    float slope;
+    int total_tiles;  // pipelined kernel
+    int plane_bytes;  // brickvox * 16
+};
+
+// Epilogue shared by both kernels (C/D map of the 32x32 MFMA: col = lane&31 = voxel,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5) = cout).
+template <int MF, int NF>
+__device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const ConvArgsH &p, int n, int oz0, int oy0,
+                                                  int ox0, int co_blk, float *red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
+    float s1[NF][16], s2[NF][16];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[nf][r] = 0.f; s2[nf][r] = 0.f; }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int v = (wave * MF + mf) * 32 + l31;
+        const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
+        const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
+        half_t *orow = p.out + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + 4 * half;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bias = *(const f32x4 *)(p.bias + co_blk + nf * 32 + 8 * g + 4 * half);
+                f16x4 val;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float x = acc[mf][nf][4 * g + k] + bias[k];
+                    if (p.act == ACT_LRELU) x = x > 0.f ? x : x * p.slope;
+                    val[k] = (half_t)x;
+                    if (ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
+                }
+                if (ok) *(f16x4 *)(orow + nf * 32 + 8 * g) = val;
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = s1[nf][r], b = s2[nf][r];
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+                if (l31 == 0) {
+                    const int c = nf * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    red[(wave * NF * 32 + c) * 2 + 0] = a;
+                    red[(wave * NF * 32 + c) * 2 + 1] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < NF * 32 * 2) {
+            const int c = tid >> 1, k = tid & 1;
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
+            atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, tot);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ simple kernel (stride 1 | 2)
+template <int STRIDE, int MF, int NF>
+__global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int n = (int)fdiv((uint32_t)bid, p.div_tiles_per_n);
+    const int t = bid - n * (int)p.div_tiles_per_n.d;
+    const int tzy = (int)fdiv((uint32_t)t, p.div_tiles_x);
+    const int tile_x = t - tzy * p.tiles_x;
+    const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
+    const int tile_y = tzy - tile_z * p.tiles_y;
+    const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
+    const int oz0 = tile_z << p.lz, oy0 = tile_y << p.ly, ox0 = tile_x << p.lx;
+    const int iz0 = oz0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+    const int IX = p.IX, IY = p.IY;
+    const int brickvox = IX * IY * p.IZ;
+    const int npieces = 2 * brickvox;
+
+    int a_base[MF];  // bytes
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int v = (wave * MF + mf) * 32 + l31;
+        const int x = v & TXm, y = (v >> p.lx) & TYm, z = v >> (p.lx + p.ly);
+        a_base[mf] = half * p.plane_bytes + ((z * STRIDE * IY + y * STRIDE) * IX + x * STRIDE) * 16;
+    }
+    f32x16 acc[MF][NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+
+    const half_t *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512) + lane * 8;
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const int cglob = ch * 16;
+        const half_t *src; int Csrc, coff;
+        if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
+        else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
+        src += (size_t)n * p.Di * p.Hi * p.Wi * Csrc + coff;
+        constexpr int U = 4;
+        for (int i0 = tid; i0 < npieces; i0 += 256 * U) {
+            f32x4 v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256;
+                const int bv = i >> 1, q = i & 1;
+                const int r = (int)fdiv((uint32_t)bv, p.div_IX);
+                const int bx = bv - r * IX;
+                const int bz = (int)fdiv((uint32_t)r, p.div_IY);
+                const int by = r - bz * IY;
+                const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+                const bool ok = (i < npieces) && ((unsigned)iz < (unsigned)p.Di) && ((unsigned)iy < (unsigned)p.Hi) &&
+                                ((unsigned)ix < (unsigned)p.Wi);
+                dst[u] = (i < npieces) ? q * p.plane_bytes + bv * 16 : -1;
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (ok) val = *(const f32x4 *)(src + ((size_t)(iz * p.Hi + iy) * p.Wi + ix) * Csrc + q * 8);
+                v[u] = val;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0) *(f32x4 *)(lds_raw + dst[u]) = v[u];
+        }
+        __syncthreads();
+        const half_t *wch = wblk + (size_t)ch * (27 * NF * 512);
+        f16x8 a_cur[MF], b_cur[NF], a_nxt[MF], b_nxt[NF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) a_cur[mf] = *(const f16x8 *)(lds_raw + a_base[mf]);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) b_cur[nf] = *(const f16x8 *)(wch + nf * 512);
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) {
+                const int nt = tap + 1;
+                const int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
+                const int off = ((dz * IY + dy) * IX + dx) * 16;
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) a_nxt[mf] = *(const f16x8 *)(lds_raw + a_base[mf] + off);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) b_nxt[nf] = *(const f16x8 *)(wch + (size_t)nt * (NF * 512) + nf * 512);
+            }
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_cur[nf], a_cur[mf], acc[mf][nf], 0, 0, 0);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) a_cur[mf] = a_nxt[mf];
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) b_cur[nf] = b_nxt[nf];
+        }
+        __syncthreads();
+    }
+    conv_epilogue_f16<MF, NF>(acc, p, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32, (float *)lds_raw);
+}
+
+// ------------------------------------------------------------------ pipelined persistent kernel (stride 1)
+template <int MF, int NF>
+__global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    constexpr int SLOTS = MF == 4 ? 11 : 8;  // 16-B staging pieces per thread and chunk
+    constexpr int BD = 3;                    // weight fragments fetched BD tap-steps ahead; the ring phase must
+                                             // be the same in every chunk, so BD divides 27
+    constexpr int FLIGHT = 12;               // tap-steps between a staging fetch and its LDS write
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
+    const int IX = p.IX, IY = p.IY;
+    const int brickvox = IX * IY * p.IZ;
+    const int npieces = 2 * brickvox;
+    const int buf_bytes = 2 * p.plane_bytes;
+    float *red = (float *)(lds_raw + 2 * buf_bytes);
+
+    const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x - xcd + 7) >> 3;
+    const int q8 = p.total_tiles >> 3, r8 = p.total_tiles & 7;
+    const int lo = xcd * q8 + (xcd < r8 ? xcd : r8);
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + li;
+    if (tile >= hi) return;
+
+    int a_base[MF];  // bytes
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int v = (wave * MF + mf) * 32 + l31;
+        const int x = v & TXm, y = (v >> p.lx) & TYm, z = v >> (p.lx + p.ly);
+        a_base[mf] = half * p.plane_bytes + ((z * IY + y) * IX + x) * 16;
+    }
+    const int qoff = (tid & 1) * 8;
+
+    struct TileCoord { int n, oz0, oy0, ox0; };
+    auto decode = [&](int t) {
+        TileCoord tc;
+        tc.n = (int)fdiv((uint32_t)t, p.div_tiles_per_n);
+        const int tt = t - tc.n * (int)p.div_tiles_per_n.d;
+        const int tzy = (int)fdiv((uint32_t)tt, p.div_tiles_x);
+        const int tile_x = tt - tzy * p.tiles_x;
+        const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
+        const int tile_y = tzy - tile_z * p.tiles_y;
+        tc.oz0 = tile_z << p.lz; tc.oy0 = tile_y << p.ly; tc.ox0 = tile_x << p.lx;
+        return tc;
+    };
+    auto stage_issue = [&](const TileCoord &tc, int ch, int r, int &dst, bool &inside) {
+        const int cglob = ch * 16;
+        const half_t *src; int Csrc, coff;
+        if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
+        else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
+        const int i = r * 256 + tid;
+        const int bv = i >> 1;
+        const int rr = (int)fdiv((uint32_t)bv, p.div_IX);
+        const int bx = bv - rr * IX;
+        const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
+        const int by = rr - bz * IY;
+        const int iz = tc.oz0 - 1 + bz, iy = tc.oy0 - 1 + by, ix = tc.ox0 - 1 + bx;
+        dst = (i < npieces) ? (i & 1) * p.plane_bytes + bv * 16 : -1;
+        inside = (i < npieces) && ((unsigned)iz < (unsigned)p.Di) && ((unsigned)iy < (unsigned)p.Hi) &&
+                 ((unsigned)ix < (unsigned)p.Wi);
+        size_t off = ((((size_t)tc.n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * Csrc + coff + qoff;
+        off = inside ? off : 0;
+        return *(const f32x4 *)(src + off);
+    };
+
+    f32x16 acc[MF][NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+
+    const half_t *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512) + lane * 8;
+    const int co_blk = (int)blockIdx.y * NF * 32;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    TileCoord cur = decode(tile);
+#pragma unroll
+    for (int r = 0; r < SLOTS; ++r) {
+        bool inside; int dst;
+        const f32x4 v = stage_issue(cur, 0, r, dst, inside);
+        if (dst >= 0) *(f32x4 *)(lds_raw + dst) = inside ? v : zero4;
+    }
+    f16x8 bq[BD][NF];
+#pragma unroll
+    for (int k = 0; k < BD; ++k)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) bq[k][nf] = *(const f16x8 *)(wblk + (size_t)k * (NF * 512) + nf * 512);
+    __syncthreads();
+
+    int ch = 0, buf = 0;
+    while (true) {
+        int ntile = tile, nch = ch + 1;
+        if (nch == p.nchunks) { nch = 0; ntile = tile + nl; }
+        const bool have_next = ntile < hi;
+        const TileCoord nxt = (nch == 0 && have_next) ? decode(ntile) : cur;
+        const int nch_eff = have_next ? nch : ch;
+        const char *bufc = lds_raw + buf * buf_bytes;
+        char *bufn = lds_raw + (buf ^ 1) * buf_bytes;
+        const half_t *wch = wblk + (size_t)ch * (27 * NF * 512);
+        const half_t *wnx = wblk + (size_t)nch_eff * (27 * NF * 512);
+
+        f16x8 a[2][MF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) a[0][mf] = *(const f16x8 *)(bufc + a_base[mf]);
+        f32x4 st_v[SLOTS];
+        int st_dst[SLOTS];
+        bool st_in[SLOTS];
+
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) {
+                const int nt = tap + 1;
+                const int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
+                const int off = ((dz * IY + dy) * IX + dx) * 16;
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) a[(tap + 1) & 1][mf] = *(const f16x8 *)(bufc + a_base[mf] + off);
+            }
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[tap % BD][nf], a[tap & 1][mf], acc[mf][nf], 0, 0, 0);
+            {
+                const int k = tap + BD;
+                const half_t *wsrc = (k < 27) ? wch + (size_t)k * (NF * 512) : wnx + (size_t)(k - 27) * (NF * 512);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) bq[tap % BD][nf] = *(const f16x8 *)(wsrc + nf * 512);
+            }
+            if (tap < SLOTS) st_v[tap] = stage_issue(nxt, nch_eff, tap, st_dst[tap], st_in[tap]);
+#pragma unroll
+            for (int r = 0; r < SLOTS; ++r) {
+                const int wr = r + FLIGHT < 26 ? r + FLIGHT : 26;
+                if (wr == tap && have_next && st_dst[r] >= 0) *(f32x4 *)(bufn + st_dst[r]) = st_in[r] ? st_v[r] : zero4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+
+        if (ch == p.nchunks - 1) {
+            conv_epilogue_f16<MF, NF>(acc, p, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+        }
+        if (!have_next) break;
+        tile = ntile; ch = nch; cur = nxt; buf ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+// Packed layout (halfs): [cout_block][chunk][tap][nf][lane 0..63][j 0..7] with
+//   cout = (cout_block*NF + nf)*32 + (lane&31),  cin = chunk*16 + (lane>>5)*8 + j.
+int conv_weights_upload_f16(const float *w_host, const float *bias_host, int cin, int cin_pad, int cout, int stride,
+                            ConvWeightsH *out) {
+    MI355_REQUIRE(stride == 1 || stride == 2, "conv stride %d unsupported", stride);
+    MI355_REQUIRE(cin_pad >= cin && cin_pad % 16 == 0, "fp16 conv needs cin_pad %% 16 == 0 (got %d for cin %d)", cin_pad, cin);
+    MI355_REQUIRE(cout % 32 == 0, "fp16 conv needs cout %% 32 == 0 (got %d)", cout);
+    ConvWeightsH cw;
+    cw.cin = cin; cw.cin_pad = cin_pad; cw.cout = cout; cw.stride = stride;
+    cw.nf = (cout % 64 == 0) ? 2 : 1;
+    const int nchunks = cin_pad / 16, nblk = cout / (32 * cw.nf);
+    std::vector<half_t> packed((size_t)nblk * nchunks * 27 * cw.nf * 512);
+    size_t o = 0;
+    for (int b = 0; b < nblk; ++b)
+        for (int ch = 0; ch < nchunks; ++ch)
+            for (int tap = 0; tap < 27; ++tap)
+                for (int f = 0; f < cw.nf; ++f)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j, ++o) {
+                            const int co = (b * cw.nf + f) * 32 + (lane & 31);
+                            const int ci = ch * 16 + (lane >> 5) * 8 + j;
+                            packed[o] = (half_t)((ci < cin) ? w_host[((size_t)co * cin + ci) * 27 + tap] : 0.f);
+                        }
+    MI355_HIP(hipMalloc(&cw.wp_dev, packed.size() * sizeof(half_t)));
+    MI355_HIP(hipMemcpy(cw.wp_dev, packed.data(), packed.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    MI355_HIP(hipMalloc(&cw.bias_dev, cout * sizeof(float)));
+    if (bias_host) MI355_HIP(hipMemcpy(cw.bias_dev, bias_host, cout * sizeof(float), hipMemcpyHostToDevice));
+    else MI355_HIP(hipMemset(cw.bias_dev, 0, cout * sizeof(float)));
+    *out = cw;
+    return MI355_OK;
+}
+
+void conv_weights_free_f16(ConvWeightsH *w) {
+    if (w->wp_dev) (void)hipFree(w->wp_dev);
+    if (w->bias_dev) (void)hipFree(w->bias_dev);
+    *w = ConvWeightsH();
+}
+
+static void choose_tile_h(int Do, int Ho, int Wo, int stride, int voxels, int *lz, int *ly, int *lx) {
+    auto p2cap = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    const int cz = p2cap(Do), cy = p2cap(Ho), cx = p2cap(Wo);
+    const int L = ilog2_exact(voxels);
+    int x = cx < 5 ? cx : 5;
+    if (x > L) x = L;
+    long best = -1;
+    int bz = L - x, by = 0;
+    for (int y = 0; x + y <= L; ++y) {
+        const int z = L - x - y;
+        const int oy = y > cy ? y - cy : 0, oz = z > cz ? z - cz : 0;
+        const long brick = (long)(((1 << y) - 1) * stride + 3) * (((1 << z) - 1) * stride + 3);
+        const long cost = ((long)(oy + oz) << 32) + brick;
+        if (best < 0 || cost < best) { best = cost; bz = z; by = y; }
+    }
+    *lz = bz; *ly = by; *lx = x;
+}
+
+static void fill_geometry_h(ConvArgsH &a, int st, int voxels) {
+    choose_tile_h(a.Do, a.Ho, a.Wo, st, voxels, &a.lz, &a.ly, &a.lx);
+    const int TX = 1 << a.lx, TY = 1 << a.ly, TZ = 1 << a.lz;
+    a.tiles_x = ceil_div(a.Wo, TX); a.tiles_y = ceil_div(a.Ho, TY); a.tiles_z = ceil_div(a.Do, TZ);
+    a.IX = (TX - 1) * st + 3; a.IY = (TY - 1) * st + 3; a.IZ = (TZ - 1) * st + 3;
+    a.div_tiles_per_n = make_fastdiv(a.tiles_x * a.tiles_y * a.tiles_z);
+    a.div_tiles_x = make_fastdiv(a.tiles_x);
+    a.div_tiles_y = make_fastdiv(a.tiles_y);
+    a.div_IX = make_fastdiv(a.IX);
+    a.div_IY = make_fastdiv(a.IY);
+    a.plane_bytes = a.IX * a.IY * a.IZ * 16;
+}
+
+template <typename K>
+static int launch_h(K kern, const ConvArgsH &a, dim3 grid, size_t lds_bytes, hipStream_t s, size_t *attr_bytes) {
+    if (lds_bytes > *attr_bytes) {
+        MI355_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        *attr_bytes = lds_bytes;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, a);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+static bool use_pipe_h() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MI355_CONV_IMPL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+
+int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, const char **kernel_name) {
+    MI355_REQUIRE(c.C0 + c.C1 == w.cin_pad, "conv input channels %d+%d != %d", c.C0, c.C1, w.cin_pad);
+    MI355_REQUIRE(c.C0 % 16 == 0 && c.C1 % 16 == 0, "fp16 concat split %d/%d not a multiple of 16", c.C0, c.C1);
+    MI355_REQUIRE(c.C1 == 0 || c.in1 != nullptr, "second conv input missing");
+    ConvArgsH a;
+    a.in0 = c.in0; a.in1 = c.in1; a.C0 = c.C0; a.C1 = c.C1;
+    a.wp = w.wp_dev; a.bias = w.bias_dev; a.out = c.out; a.stats = c.stats;
+    a.N = c.N; a.Di = c.Di; a.Hi = c.Hi; a.Wi = c.Wi;
+    const int st = w.stride;
+    a.Do = (c.Di - 1) / st + 1; a.Ho = (c.Hi - 1) / st + 1; a.Wo = (c.Wi - 1) / st + 1;
+    a.Cout = w.cout;
+    a.nchunks = w.cin_pad / 16;
+    a.act = c.act; a.slope = c.slope;
+    a.total_tiles = 0;
+    const int gy = w.cout / (32 * w.nf);
+    static size_t attr[8] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+    if (st == 1 && use_pipe_h()) {
+        int MF = 4;
+        fill_geometry_h(a, 1, 128 * MF);
+        long tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * c.N;
+        if (tiles * gy < 512 || a.IX * a.IY * a.IZ > 11 * 128 || w.nf == 2) {
+            MF = 2;
+            fill_geometry_h(a, 1, 128 * MF);
+            tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * c.N;
+        }
+        MI355_REQUIRE(tiles < (1l << 30), "conv grid too large");
+        MI355_REQUIRE(a.IX * a.IY * a.IZ <= (MF == 4 ? 11 : 8) * 128, "conv brick exceeds the staging slots");
+        a.total_tiles = (int)tiles;
+        const size_t lds_bytes = (size_t)4 * a.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float);
+        MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
+        int gx = 512 / gy;
+        gx = gx < 8 ? 8 : (gx / 8) * 8;
+        const int need = (int)((tiles + 7) / 8) * 8;
+        if (gx > need) gx = need;
+        dim3 grid(gx, gy);
+        if (kernel_name) *kernel_name = w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<*, 1>" : "conv3_f16_mfma_pipe_kernel<*, 2>";
+        if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1>, a, grid, lds_bytes, s, &attr[0]);
+        if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1>, a, grid, lds_bytes, s, &attr[1]);
+        return launch_h(conv3_f16_mfma_pipe_kernel<2, 2>, a, grid, lds_bytes, s, &attr[2]);
+    }
+    const int MF = (st == 1) ? 2 : 1;
+    fill_geometry_h(a, st, 128 * MF);
+    const long tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * c.N;
+    MI355_REQUIRE(tiles < (1l << 30), "conv grid too large");
+    size_t lds_bytes = (size_t)2 * a.plane_bytes;
+    if (lds_bytes < 4096) lds_bytes = 4096;
+    MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
+    dim3 grid((unsigned)tiles, gy);
+    if (st == 1) {
+        if (kernel_name) *kernel_name = w.nf == 1 ? "conv3_f16_mfma_kernel<1, 2, 1>" : "conv3_f16_mfma_kernel<1, 2, 2>";
+        if (w.nf == 1) return launch_h(conv3_f16_mfma_kernel<1, 2, 1>, a, grid, lds_bytes, s, &attr[3]);
+        return launch_h(conv3_f16_mfma_kernel<1, 2, 2>, a, grid, lds_bytes, s, &attr[4]);
+    }
+    if (kernel_name) *kernel_name = w.nf == 1 ? "conv3_f16_mfma_kernel<2, 1, 1>" : "conv3_f16_mfma_kernel<2, 1, 2>";
+    if (w.nf == 1) return launch_h(conv3_f16_mfma_kernel<2, 1, 1>, a, grid, lds_bytes, s, &attr[5]);
+    return launch_h(conv3_f16_mfma_kernel<2, 1, 2>, a, grid, lds_bytes, s, &attr[6]);
+}
+
+}  // namespace mi355

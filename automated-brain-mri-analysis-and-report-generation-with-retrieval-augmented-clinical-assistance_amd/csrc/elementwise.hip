@@ -8,6 +8,21 @@
 
 namespace mi355 {
 
+// 4 consecutive elements of T (float | _Float16) <-> f32x4
+template <typename T> __device__ __forceinline__ f32x4 load4(const T *p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float *p) { return *(const f32x4 *)p; }
+template <> __device__ __forceinline__ f32x4 load4<_Float16>(const _Float16 *p) {
+    const f16x4 h = *(const f16x4 *)p;
+    f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store4(T *p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float *p, f32x4 v) { *(f32x4 *)p = v; }
+template <> __device__ __forceinline__ void store4<_Float16>(_Float16 *p, f32x4 v) {
+    f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    *(f16x4 *)p = h;
+}
+
 // ------------------------------------------------------------------ Instance / Group norm
 // Finalises the (sum, sum^2) the conv epilogue accumulated into per-(n, channel) affine
 // coefficients: y = x*scale + shift.  Replaces the statistics half of
@@ -53,14 +68,15 @@ int norm_finalize(const double *stats, int N, int C, int64_t count, int kind, in
     return MI355_OK;
 }
 
-__global__ void norm_apply_kernel(f32x4 *x, int64_t total4, int64_t VC4, int C4, const f32x4 *scale,
-                                  const f32x4 *shift, int act, float slope) {
+template <typename T>
+__global__ void norm_apply_kernel(T *x, int64_t total4, int64_t VC4, int C4, const f32x4 *scale, const f32x4 *shift,
+                                  int act, float slope) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = i / VC4;
         const int c4 = (int)(i % C4);
         const f32x4 sc = scale[n * C4 + c4], sh = shift[n * C4 + c4];
-        f32x4 v = x[i];
+        f32x4 v = load4<T>(x + i * 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float y = v[k] * sc[k] + sh[k];
@@ -68,18 +84,22 @@ __global__ void norm_apply_kernel(f32x4 *x, int64_t total4, int64_t VC4, int C4,
                 y = y > 0.f ? y : y * slope;
             v[k] = y;
         }
-        x[i] = v;
+        store4<T>(x + i * 4, v);
     }
 }
 
-int norm_apply(float *x, int N, int64_t V, int C, const float *scale, const float *shift, int act,
+int norm_apply(void *x, int dtype, int N, int64_t V, int C, const float *scale, const float *shift, int act,
                float slope, hipStream_t s) {
     MI355_REQUIRE(C % 4 == 0, "norm_apply: C=%d", C);
     const int64_t total4 = (int64_t)N * V * C / 4;
     int64_t blocks = (total4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (f32x4 *)x, total4,
-                       V * C / 4, C / 4, (const f32x4 *)scale, (const f32x4 *)shift, act, slope);
+    if (dtype == MI355_F16)
+        hipLaunchKernelGGL(norm_apply_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, (_Float16 *)x, total4,
+                           V * C / 4, C / 4, (const f32x4 *)scale, (const f32x4 *)shift, act, slope);
+    else
+        hipLaunchKernelGGL(norm_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float *)x, total4,
+                           V * C / 4, C / 4, (const f32x4 *)scale, (const f32x4 *)shift, act, slope);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
@@ -93,8 +113,9 @@ struct TileList {
     TileDesc t[MAX_SAMPLES];
 };
 
+template <typename T>
 __global__ void extract_tiles_kernel(const float *vol, int C, int Z, int Y, int X, int padz, int pady,
-                                     int padx, TileList tl, int P0, int P1, int P2, int Cpad, float *x) {
+                                     int padx, TileList tl, int P0, int P1, int P2, int Cpad, T *x) {
     const int b = blockIdx.y;
     const TileDesc td = tl.t[b];
     const int64_t PV = (int64_t)P0 * P1 * P2;
@@ -108,15 +129,15 @@ __global__ void extract_tiles_kernel(const float *vol, int C, int Z, int Y, int 
         const int sx = (td.mirror & 4) ? P2 - 1 - px : px;
         const int gz = td.z0 + sz - padz, gy = td.y0 + sy - pady, gx = td.x0 + sx - padx;
         const bool ok = (unsigned)gz < (unsigned)Z && (unsigned)gy < (unsigned)Y && (unsigned)gx < (unsigned)X;
-        float *dst = x + ((int64_t)b * PV + v) * Cpad;
+        T *dst = x + ((int64_t)b * PV + v) * Cpad;
         const int64_t g = ((int64_t)gz * Y + gy) * X + gx;
         for (int c = 0; c < Cpad; ++c)
-            dst[c] = (ok && c < C) ? vol[c * ZYX + g] : 0.f;
+            dst[c] = (T)((ok && c < C) ? vol[c * ZYX + g] : 0.f);
     }
 }
 
 int extract_tiles(const float *vol, int C, int Z, int Y, int X, int padz, int pady, int padx,
-                  const TileDesc *tiles_host, int n_samples, int P0, int P1, int P2, int Cpad, float *x,
+                  const TileDesc *tiles_host, int n_samples, int P0, int P1, int P2, int Cpad, void *x, int dtype,
                   hipStream_t s) {
     MI355_REQUIRE(n_samples > 0 && n_samples <= MAX_SAMPLES, "extract_tiles: %d samples (max %d)", n_samples, MAX_SAMPLES);
     TileList tl;
@@ -124,25 +145,33 @@ int extract_tiles(const float *vol, int C, int Z, int Y, int X, int padz, int pa
     const int64_t PV = (int64_t)P0 * P1 * P2;
     int64_t bx = (PV + 255) / 256;
     if (bx > 4096) bx = 4096;
-    hipLaunchKernelGGL(extract_tiles_kernel, dim3((unsigned)bx, n_samples), dim3(256), 0, s, vol, C, Z, Y, X,
-                       padz, pady, padx, tl, P0, P1, P2, Cpad, x);
+    if (dtype == MI355_F16)
+        hipLaunchKernelGGL(extract_tiles_kernel<_Float16>, dim3((unsigned)bx, n_samples), dim3(256), 0, s, vol, C, Z, Y,
+                           X, padz, pady, padx, tl, P0, P1, P2, Cpad, (_Float16 *)x);
+    else
+        hipLaunchKernelGGL(extract_tiles_kernel<float>, dim3((unsigned)bx, n_samples), dim3(256), 0, s, vol, C, Z, Y, X,
+                           padz, pady, padx, tl, P0, P1, P2, Cpad, (float *)x);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
 
-__global__ void nchw_to_ndhwc_kernel(const float *x, int C, int64_t V, int Cpad, float *y, int64_t total) {
+template <typename T>
+__global__ void nchw_to_ndhwc_kernel(const float *x, int C, int64_t V, int Cpad, T *y, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = i / V, v = i - n * V;
         for (int c = 0; c < Cpad; ++c)
-            y[i * Cpad + c] = c < C ? x[(n * C + c) * V + v] : 0.f;
+            y[i * Cpad + c] = (T)(c < C ? x[(n * C + c) * V + v] : 0.f);
     }
 }
 
-int nchw_to_ndhwc(const float *x, int N, int C, int64_t V, int Cpad, float *y, hipStream_t s) {
+int nchw_to_ndhwc(const float *x, int N, int C, int64_t V, int Cpad, void *y, int dtype, hipStream_t s) {
     const int64_t total = (int64_t)N * V;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(nchw_to_ndhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, C, V, Cpad, y, total);
+    if (dtype == MI355_F16)
+        hipLaunchKernelGGL(nchw_to_ndhwc_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, x, C, V, Cpad, (_Float16 *)y, total);
+    else
+        hipLaunchKernelGGL(nchw_to_ndhwc_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, x, C, V, Cpad, (float *)y, total);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
@@ -173,13 +202,14 @@ constexpr int HEAD_MAX_CLS = 8;
 
 // 8 lanes cooperate on one voxel: each takes every 8th 16-B channel quad, partial dot products
 // are combined with three xor-shuffles.  Returns the logits in every lane of the group.
-__device__ __forceinline__ void head_dot(const float *feat_vox, const float *w, const float *b, int C,
+template <typename T>
+__device__ __forceinline__ void head_dot(const T *feat_vox, const float *w, const float *b, int C,
                                          int ncls, int q, float *logit) {
     float part[HEAD_MAX_CLS];
 #pragma unroll
     for (int k = 0; k < HEAD_MAX_CLS; ++k) part[k] = 0.f;
     for (int c4 = q; c4 * 4 < C; c4 += 8) {
-        const f32x4 f = *(const f32x4 *)(feat_vox + c4 * 4);
+        const f32x4 f = load4<T>(feat_vox + c4 * 4);
 #pragma unroll
         for (int k = 0; k < HEAD_MAX_CLS; ++k)
             if (k < ncls) {
@@ -197,13 +227,14 @@ __device__ __forceinline__ void head_dot(const float *feat_vox, const float *w, 
     }
 }
 
-__global__ void head_logits_kernel(const float *feat, const float *w, const float *b, int C, int ncls,
+template <typename T>
+__global__ void head_logits_kernel(const T *feat, const float *w, const float *b, int C, int ncls,
                                    int64_t V, int64_t total, float *logits) {
     const int q = threadIdx.x & 7;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < total;
          i += ((int64_t)gridDim.x * blockDim.x) >> 3) {
         float lg[HEAD_MAX_CLS];
-        head_dot(feat + i * C, w, b, C, ncls, q, lg);
+        head_dot<T>(feat + i * C, w, b, C, ncls, q, lg);
         const int64_t n = i / V, v = i - n * V;
 #pragma unroll
         for (int k = 0; k < HEAD_MAX_CLS; ++k)
@@ -212,13 +243,17 @@ __global__ void head_logits_kernel(const float *feat, const float *w, const floa
     }
 }
 
-int head_logits(const HeadWeights &w, const float *feat, int N, int64_t V, float *logits, hipStream_t s) {
+int head_logits(const HeadWeights &w, const void *feat, int dtype, int N, int64_t V, float *logits, hipStream_t s) {
     const int64_t total = (int64_t)N * V;
     MI355_REQUIRE(total % 32 == 0, "head_logits: voxel count %ld not a multiple of 32", (long)total);
     int64_t blocks = (total * 8 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(head_logits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, feat, w.w_dev, w.b_dev,
-                       w.cin, w.ncls, V, total, logits);
+    if (dtype == MI355_F16)
+        hipLaunchKernelGGL(head_logits_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, (const _Float16 *)feat,
+                           w.w_dev, w.b_dev, w.cin, w.ncls, V, total, logits);
+    else
+        hipLaunchKernelGGL(head_logits_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float *)feat, w.w_dev,
+                           w.b_dev, w.cin, w.ncls, V, total, logits);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
@@ -232,7 +267,8 @@ struct MirrorList {
 //   result = sum_m  mult * flip_back(nonlin(net(flip_m(x))))      mult = 1/n_mirrors, m in list order
 //   result *= gaussian ; aggregated[:, tile] += result ; normaliser[tile] += gaussian
 // feat holds the last decoder feature map of the n_mirrors forwards of this tile.
-__global__ void head_aggregate_kernel(const float *feat, const float *w, const float *b, int C, int ncls,
+template <typename T>
+__global__ void head_aggregate_kernel(const T *feat, const float *w, const float *b, int C, int ncls,
                                       MirrorList ml, int P0, int P1, int P2, int nonlin, const float *gauss,
                                       float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0) {
     const int q = threadIdx.x & 7;
@@ -254,7 +290,7 @@ __global__ void head_aggregate_kernel(const float *feat, const float *w, const f
             const int sx = (m & 4) ? P2 - 1 - px : px;
             const int64_t sv = ((int64_t)sz * P1 + sy) * P2 + sx;
             float lg[HEAD_MAX_CLS];
-            head_dot(feat + ((int64_t)mi * PV + sv) * C, w, b, C, ncls, q, lg);
+            head_dot<T>(feat + ((int64_t)mi * PV + sv) * C, w, b, C, ncls, q, lg);
             if (nonlin == MI355_NONLIN_SIGMOID) {
 #pragma unroll
                 for (int k = 0; k < HEAD_MAX_CLS; ++k) lg[k] = 1.0f / (1.0f + expf(-lg[k]));
@@ -282,7 +318,7 @@ __global__ void head_aggregate_kernel(const float *feat, const float *w, const f
     }
 }
 
-int head_aggregate(const HeadWeights &w, const float *feat, int first_sample, const int *mirrors_host,
+int head_aggregate(const HeadWeights &w, const void *feat, int dtype, int first_sample, const int *mirrors_host,
                    int n_mirrors, int P0, int P1, int P2, int nonlin, const float *gauss, float *agg,
                    float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, hipStream_t s) {
     MI355_REQUIRE(n_mirrors >= 1 && n_mirrors <= 8, "head_aggregate: %d mirrors", n_mirrors);
@@ -294,9 +330,14 @@ int head_aggregate(const HeadWeights &w, const float *feat, int first_sample, co
     MI355_REQUIRE(PV % 32 == 0, "head_aggregate: patch voxels %ld not a multiple of 32", (long)PV);
     int64_t blocks = (PV * 8 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(head_aggregate_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                       feat + (size_t)first_sample * PV * w.cin, w.w_dev, w.b_dev, w.cin, w.ncls, ml, P0, P1, P2,
-                       nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0);
+    if (dtype == MI355_F16)
+        hipLaunchKernelGGL(head_aggregate_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           (const _Float16 *)feat + (size_t)first_sample * PV * w.cin, w.w_dev, w.b_dev, w.cin, w.ncls, ml,
+                           P0, P1, P2, nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0);
+    else
+        hipLaunchKernelGGL(head_aggregate_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           (const float *)feat + (size_t)first_sample * PV * w.cin, w.w_dev, w.b_dev, w.cin, w.ncls, ml, P0,
+                           P1, P2, nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }

@@ -38,6 +38,26 @@ struct ConvCall {
 int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s);
 int conv3d_direct_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s);
 
+// fp16 storage / fp32 accumulate variants (conv3d_f16.hip)
+struct ConvWeightsH {
+    int cin = 0, cin_pad = 0, cout = 0, stride = 1, nf = 1;
+    _Float16 *wp_dev = nullptr;
+    float *bias_dev = nullptr;
+};
+int conv_weights_upload_f16(const float *w_host, const float *bias_host, int cin, int cin_pad, int cout, int stride,
+                            ConvWeightsH *out);
+void conv_weights_free_f16(ConvWeightsH *w);
+struct ConvCallH {
+    const _Float16 *in0 = nullptr, *in1 = nullptr;
+    int C0 = 0, C1 = 0;
+    int N = 0, Di = 0, Hi = 0, Wi = 0;
+    _Float16 *out = nullptr;
+    double *stats = nullptr;
+    int act = ACT_NONE;
+    float slope = 0.01f;
+};
+int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, const char **kernel_name = nullptr);
+
 // ---------------------------------------------------------------- transposed conv k=2 s=2
 struct TConvWeights {
     int cin = 0, cout = 0;
@@ -48,13 +68,21 @@ void tconv_weights_free(TConvWeights *w);
 // in [N,D,H,W,Cin] -> out [N,2D,2H,2W,Cout]
 int tconv2_mfma_f32(const TConvWeights &w, const float *in, int N, int D, int H, int W, float *out,
                     hipStream_t s);
+struct TConvWeightsH {
+    int cin = 0, cout = 0;
+    _Float16 *wp_dev = nullptr;
+};
+int tconv_weights_upload_f16(const float *w_host, int cin, int cout, TConvWeightsH *out);
+void tconv_weights_free_f16(TConvWeightsH *w);
+int tconv2_mfma_f16(const TConvWeightsH &w, const _Float16 *in, int N, int D, int H, int W, _Float16 *out,
+                    hipStream_t s);
 
 // ---------------------------------------------------------------- normalisation
 // stats [N][C][2] doubles -> scale/shift [N][C] so that y = x*scale + shift.
 int norm_finalize(const double *stats, int N, int C, int64_t count, int kind, int groups, float eps,
                   const float *gamma, const float *beta, float *scale, float *shift, hipStream_t s);
 // in place: x = act(x*scale[n][c] + shift[n][c]) over [N][V][C]
-int norm_apply(float *x, int N, int64_t V, int C, const float *scale, const float *shift, int act,
+int norm_apply(void *x, int dtype, int N, int64_t V, int C, const float *scale, const float *shift, int act,
                float slope, hipStream_t s);
 
 // ---------------------------------------------------------------- tiles / head / aggregate
@@ -65,10 +93,10 @@ struct TileDesc {  // one forward sample = one (tile, mirror)
 // vol [C][Z][Y][X] (unpadded; pad offsets give where it sits in the padded volume)
 // -> x [n_samples][P0][P1][P2][Cpad] (channels >= C are zero)
 int extract_tiles(const float *vol, int C, int Z, int Y, int X, int padz, int pady, int padx,
-                  const TileDesc *tiles_host, int n_samples, int P0, int P1, int P2, int Cpad, float *x,
+                  const TileDesc *tiles_host, int n_samples, int P0, int P1, int P2, int Cpad, void *x, int dtype,
                   hipStream_t s);
 // NCDHW -> NDHWC(Cpad) for the plain forward API
-int nchw_to_ndhwc(const float *x, int N, int C, int64_t V, int Cpad, float *y, hipStream_t s);
+int nchw_to_ndhwc(const float *x, int N, int C, int64_t V, int Cpad, void *y, int dtype, hipStream_t s);
 
 struct HeadWeights {
     int cin = 0, ncls = 0;
@@ -78,10 +106,10 @@ struct HeadWeights {
 int head_weights_upload(const float *w_host, const float *b_host, int cin, int ncls, HeadWeights *out);
 void head_weights_free(HeadWeights *w);
 // feat [N][V][C] -> logits [N][ncls][V]
-int head_logits(const HeadWeights &w, const float *feat, int N, int64_t V, float *logits, hipStream_t s);
+int head_logits(const HeadWeights &w, const void *feat, int dtype, int N, int64_t V, float *logits, hipStream_t s);
 // One tile: result = sum_m (1/n_mirrors) * flip_back(nonlin(head(feat[first_sample+m])));
 // agg[c][tile] += result * gauss ; cnt[tile] += gauss (cnt may be null).
-int head_aggregate(const HeadWeights &w, const float *feat, int first_sample, const int *mirrors_host,
+int head_aggregate(const HeadWeights &w, const void *feat, int dtype, int first_sample, const int *mirrors_host,
                    int n_mirrors, int P0, int P1, int P2, int nonlin, const float *gauss, float *agg,
                    float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, hipStream_t s);
 // probs[c][z][y][x] (+)= agg[c][z+pz][y+py][x+px] / cnt[...]; then optional scale (fold mean)

@@ -119,4 +119,104 @@ int tconv2_mfma_f32(const TConvWeights &w, const float *in, int N, int D, int H,
     return MI355_OK;
 }
 
+// ------------------------------------------------------------------ fp16 storage variant
+// D[cout][voxel] = W^T x X per output parity on v_mfma_f32_32x32x16_f16: weights are the A operand (lane: cout l&31,
+// channels 8*(l>>5)..+7), input voxels the B operand read straight from global (16 B per lane); a lane ends up with
+// 4 consecutive couts per register quad -> 8-byte stores.
+template <int MF>
+__global__ __launch_bounds__(256) void tconv2_f16_mfma_kernel(const _Float16 *__restrict__ in,
+                                                             const _Float16 *__restrict__ wp, _Float16 *out, int M,
+                                                             int Cin, int Cout, int D, int H, int W, FastDiv divW,
+                                                             FastDiv divH, FastDiv divD) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nblk = Cout >> 5;
+    const int pos = (int)blockIdx.y / nblk, nb = (int)blockIdx.y - pos * nblk;
+    const int G = Cin >> 4;
+    const int m0 = ((int)blockIdx.x * 4 + wave) * (MF * 32);
+    const _Float16 *xrow[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        int v = m0 + mf * 32 + l31;
+        if (v >= M) v = M - 1;
+        xrow[mf] = in + (size_t)v * Cin + half * 8;
+    }
+    const _Float16 *wrow = wp + ((size_t)(pos * nblk + nb) * G) * 512 + lane * 8;
+    f32x16 acc[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mf][r] = 0.f;
+#pragma unroll 2
+    for (int g = 0; g < G; ++g) {
+        const f16x8 wf = *(const f16x8 *)(wrow + (size_t)g * 512);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const f16x8 xf = *(const f16x8 *)(xrow[mf] + g * 16);
+            acc[mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[mf], 0, 0, 0);
+        }
+    }
+    const int pa = pos >> 2, pb = (pos >> 1) & 1, pc = pos & 1;
+    const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int v = m0 + mf * 32 + l31;
+        if (v < M) {
+            const uint32_t q1 = fdiv((uint32_t)v, divW);
+            const int x = v - (int)q1 * W;
+            const uint32_t q2 = fdiv(q1, divH);
+            const int y = (int)q1 - (int)q2 * H;
+            const uint32_t n = fdiv(q2, divD);
+            const int z = (int)q2 - (int)n * D;
+            _Float16 *o = out + ((((size_t)n * Do + 2 * z + pa) * Ho + 2 * y + pb) * Wo + 2 * x + pc) * Cout + nb * 32 + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 hv = {(_Float16)acc[mf][4 * g], (_Float16)acc[mf][4 * g + 1], (_Float16)acc[mf][4 * g + 2],
+                            (_Float16)acc[mf][4 * g + 3]};
+                *(f16x4 *)(o + 8 * g) = hv;
+            }
+        }
+    }
+}
+
+// pack: [pos][cout block][g][lane][j 0..7]; cout = nb*32 + (lane&31), cin = g*16 + (lane>>5)*8 + j
+int tconv_weights_upload_f16(const float *w_host, int cin, int cout, TConvWeightsH *out) {
+    MI355_REQUIRE(cin % 16 == 0 && cout % 32 == 0, "fp16 tconv %d->%d: need cin %% 16 == 0 and cout %% 32 == 0", cin, cout);
+    const int G = cin / 16, nblk = cout / 32;
+    std::vector<_Float16> packed((size_t)8 * nblk * G * 512);
+    size_t o = 0;
+    for (int pos = 0; pos < 8; ++pos)
+        for (int nb = 0; nb < nblk; ++nb)
+            for (int g = 0; g < G; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j, ++o) {
+                        const int co = nb * 32 + (lane & 31);
+                        const int ci = g * 16 + (lane >> 5) * 8 + j;
+                        packed[o] = (_Float16)w_host[((size_t)ci * cout + co) * 8 + pos];
+                    }
+    TConvWeightsH tw;
+    tw.cin = cin; tw.cout = cout;
+    MI355_HIP(hipMalloc(&tw.wp_dev, packed.size() * sizeof(_Float16)));
+    MI355_HIP(hipMemcpy(tw.wp_dev, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    *out = tw;
+    return MI355_OK;
+}
+
+void tconv_weights_free_f16(TConvWeightsH *w) {
+    if (w->wp_dev) (void)hipFree(w->wp_dev);
+    *w = TConvWeightsH();
+}
+
+int tconv2_mfma_f16(const TConvWeightsH &w, const _Float16 *in, int N, int D, int H, int W, _Float16 *out,
+                    hipStream_t s) {
+    const long M = (long)N * D * H * W;
+    MI355_REQUIRE(M > 0 && M < (1l << 30), "tconv: %ld voxels out of range", M);
+    constexpr int MF = 2;
+    dim3 grid((unsigned)((M + 4 * MF * 32 - 1) / (4 * MF * 32)), 8 * (w.cout / 32));
+    hipLaunchKernelGGL(tconv2_f16_mfma_kernel<MF>, grid, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cin, w.cout, D, H,
+                       W, make_fastdiv(W), make_fastdiv(H), make_fastdiv(D));
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
 }  // namespace mi355

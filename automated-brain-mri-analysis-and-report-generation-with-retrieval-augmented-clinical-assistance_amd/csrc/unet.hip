@@ -29,7 +29,8 @@ void set_error(const char *fmt, ...) {
 }
 
 struct ConvLayer {
-    ConvWeights w;
+    ConvWeights w;     // MI355_F32
+    ConvWeightsH wh;   // MI355_F16
     float *gamma_dev = nullptr, *beta_dev = nullptr;  // Instance/GroupNorm affine, or BN scale/shift (nonlin_first)
     bool runtime_norm = false;                        // statistics needed at run time (IN / GN)
     bool post_affine = false;                         // BN that could not be folded (nonlin_first)
@@ -47,6 +48,7 @@ struct mi355_unet {
     std::vector<std::vector<ConvLayer>> enc;  // num_pool + 1 stages
     std::vector<std::vector<ConvLayer>> dec;  // num_pool stages
     std::vector<TConvWeights> tu;
+    std::vector<TConvWeightsH> tuh;
     HeadWeights head;
     // activation arena: ONE per process and device, shared by every handle (handles run one after
     // the other on the caller's stream; 5 folds x 2 models would not fit 288 GB with private arenas)
@@ -118,13 +120,15 @@ static int build_conv(const mi355_unet &net, const mi355_conv_desc &d, int cin_p
         MI355_TRY(upload(g.data(), d.cout, &L.gamma_dev));
         MI355_TRY(upload(be.data(), d.cout, &L.beta_dev));
     }
-    MI355_TRY(conv_weights_upload(w.data(), b.data(), d.cin, cin_phys, d.cout, d.stride, false, &L.w));
+    if (net.dtype == MI355_F16) MI355_TRY(conv_weights_upload_f16(w.data(), b.data(), d.cin, cin_phys, d.cout, d.stride, &L.wh));
+    else MI355_TRY(conv_weights_upload(w.data(), b.data(), d.cin, cin_phys, d.cout, d.stride, false, &L.w));
     *out = L;
     return MI355_OK;
 }
 
 static void free_conv(ConvLayer *L) {
     conv_weights_free(&L->w);
+    conv_weights_free_f16(&L->wh);
     if (L->gamma_dev) (void)hipFree(L->gamma_dev);
     if (L->beta_dev) (void)hipFree(L->beta_dev);
 }
@@ -134,6 +138,7 @@ static void destroy(mi355_unet *net) {
     for (auto &st : net->enc) for (auto &L : st) free_conv(&L);
     for (auto &st : net->dec) for (auto &L : st) free_conv(&L);
     for (auto &t : net->tu) tconv_weights_free(&t);
+    for (auto &t : net->tuh) tconv_weights_free_f16(&t);
     head_weights_free(&net->head);
     if (net->gauss_dev) (void)hipFree(net->gauss_dev);
     delete net;
@@ -160,16 +165,17 @@ static int make_plan(const mi355_unet &net, int N, int D, int H, int W, Plan *pl
     }
     for (int u = 0; u < np; ++u) {
         const int l = np - 1 - u;
-        pl->maxc[l] = std::max(pl->maxc[l], net.tu[u].cout);
+        pl->maxc[l] = std::max(pl->maxc[l], net.dtype == MI355_F16 ? net.tuh[u].cout : net.tu[u].cout);
         for (auto &L : net.dec[u]) pl->maxc[l] = std::max(pl->maxc[l], L.cout);
     }
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~size_t(255); return r; };
-    pl->x0_off = take((size_t)N * pl->vox[0] * net.cin_pad * sizeof(float));
+    const size_t es = net.dtype == MI355_F16 ? 2 : 4;
+    pl->x0_off = take((size_t)N * pl->vox[0] * net.cin_pad * es);
     for (int k = 0; k < 4; ++k) pl->off[k].resize(np + 1);
     for (int l = 0; l <= np; ++l)
         for (int k = 0; k < 4; ++k)
-            pl->off[k][l] = take((size_t)N * pl->vox[l] * pl->maxc[l] * sizeof(float));
+            pl->off[k][l] = take((size_t)N * pl->vox[l] * pl->maxc[l] * es);
     pl->stats_bytes = (size_t)N * net.max_channels * 2 * sizeof(double);
     pl->stats_off = take(pl->stats_bytes);
     pl->scale_off = take((size_t)N * net.max_channels * sizeof(float));
@@ -217,53 +223,70 @@ static std::string conv_kernel_name(const ConvWeights &w) {
 }
 
 // One ConvDropoutNormNonlin / ConvDropoutNonlinNorm block.
-static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const float *in0, int C0,
-                     const float *in1, int C1, int N, int Di, int Hi, int Wi, float *out, hipStream_t s) {
-    ConvCall c;
-    c.in0 = in0; c.in1 = in1; c.C0 = C0; c.C1 = C1;
-    c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi;
-    c.out = out; c.slope = net->slope;
+static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const void *in0, int C0,
+                     const void *in1, int C1, int N, int Di, int Hi, int Wi, void *out, hipStream_t s) {
+    const bool f16 = net->dtype == MI355_F16;
     double *stats = (double *)(net->arena + pl.stats_off);
     float *scale = (float *)(net->arena + pl.scale_off), *shift = (float *)(net->arena + pl.shift_off);
+    int act = ACT_LRELU;
+    double *stats_arg = nullptr;
     if (L.runtime_norm) {
-        c.act = net->nonlin_first ? ACT_LRELU : ACT_NONE;
-        c.stats = stats;
+        act = net->nonlin_first ? ACT_LRELU : ACT_NONE;
+        stats_arg = stats;
         MI355_HIP(hipMemsetAsync(stats, 0, (size_t)N * L.cout * 2 * sizeof(double), s));
-    } else {
-        c.act = ACT_LRELU;
     }
     const int st = L.stride;
     const int64_t Vo = (int64_t)((Di - 1) / st + 1) * ((Hi - 1) / st + 1) * ((Wi - 1) / st + 1);
     {
         // algorithmic work of this launch: 2*MAC over the LOGICAL cin; input read once + output written once + weights
+        const double es = f16 ? 2.0 : 4.0;
         const double flops = 2.0 * N * Vo * L.cout * (double)L.cin * 27.0;
-        const double bytes = 4.0 * ((double)N * Di * Hi * Wi * (C0 + C1) + (double)N * Vo * L.cout + (double)L.cout * L.cin * 27.0);
-        ProfScope ps(net, s, conv_kernel_name(L.w), flops, bytes);
-        if (L.w.wp_dev) MI355_TRY(conv3d_mfma_f32(L.w, c, s));
-        else MI355_TRY(conv3d_direct_f32(L.w, c, s));
+        const double bytes = es * ((double)N * Di * Hi * Wi * (C0 + C1) + (double)N * Vo * L.cout + (double)L.cout * L.cin * 27.0);
+        if (f16) {
+            ConvCallH c;
+            c.in0 = (const _Float16 *)in0; c.in1 = (const _Float16 *)in1; c.C0 = C0; c.C1 = C1;
+            c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi; c.out = (_Float16 *)out; c.slope = net->slope;
+            c.act = act; c.stats = stats_arg;
+            const char *kname = "conv3_f16";
+            // resolve the kernel name first (cheap) so the profiler record carries it
+            ProfScope ps(net, s, L.wh.stride == 1 ? (L.wh.nf == 1 ? "conv3_f16_mfma_pipe_kernel<*, 1>" : "conv3_f16_mfma_pipe_kernel<*, 2>")
+                                                   : (L.wh.nf == 1 ? "conv3_f16_mfma_kernel<2, 1, 1>" : "conv3_f16_mfma_kernel<2, 1, 2>"),
+                         flops, bytes);
+            MI355_TRY(conv3d_mfma_f16(L.wh, c, s, &kname));
+        } else {
+            ConvCall c;
+            c.in0 = (const float *)in0; c.in1 = (const float *)in1; c.C0 = C0; c.C1 = C1;
+            c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi; c.out = (float *)out; c.slope = net->slope;
+            c.act = act; c.stats = stats_arg;
+            ProfScope ps(net, s, conv_kernel_name(L.w), flops, bytes);
+            if (L.w.wp_dev) MI355_TRY(conv3d_mfma_f32(L.w, c, s));
+            else MI355_TRY(conv3d_direct_f32(L.w, c, s));
+        }
     }
+    const double es = f16 ? 2.0 : 4.0;
     if (L.runtime_norm) {
         MI355_TRY(norm_finalize(stats, N, L.cout, Vo, net->norm, net->num_groups, net->eps, L.gamma_dev, L.beta_dev,
                                 scale, shift, s));
-        ProfScope ps(net, s, "norm_apply_kernel", 2.0 * N * Vo * L.cout, 8.0 * N * Vo * L.cout);
-        MI355_TRY(norm_apply(out, N, Vo, L.cout, scale, shift, net->nonlin_first ? ACT_NONE : ACT_LRELU, net->slope, s));
+        ProfScope ps(net, s, f16 ? "norm_apply_kernel<f16>" : "norm_apply_kernel<f32>", 2.0 * N * Vo * L.cout, 2.0 * es * N * Vo * L.cout);
+        MI355_TRY(norm_apply(out, net->dtype, N, Vo, L.cout, scale, shift, net->nonlin_first ? ACT_NONE : ACT_LRELU, net->slope, s));
     } else if (L.post_affine) {
         // BN after the nonlinearity: per-channel affine, identical for every sample
         for (int n = 0; n < N; ++n)
-            MI355_TRY(norm_apply(out + (size_t)n * Vo * L.cout, 1, Vo, L.cout, L.gamma_dev, L.beta_dev, ACT_NONE,
-                                 net->slope, s));
+            MI355_TRY(norm_apply((char *)out + (size_t)n * Vo * L.cout * (size_t)es, net->dtype, 1, Vo, L.cout, L.gamma_dev, L.beta_dev,
+                                 ACT_NONE, net->slope, s));
     }
     return MI355_OK;
 }
 
 // x0: [N,D,H,W,cin_pad] already in the arena at pl.x0_off.  Returns the last decoder feature map.
-static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H, int W, const float **feat,
+static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H, int W, const void **feat,
                             int *feat_c, hipStream_t s) {
     const int np = net->num_pool;
-    auto buf = [&](int k, int l) { return (float *)(net->arena + pl.off[k][l]); };
-    const float *cur = (const float *)(net->arena + pl.x0_off);
+    const bool f16 = net->dtype == MI355_F16;
+    auto buf = [&](int k, int l) { return (void *)(net->arena + pl.off[k][l]); };
+    const void *cur = (const void *)(net->arena + pl.x0_off);
     int curC = net->cin_pad;
-    std::vector<const float *> skip(np);
+    std::vector<const void *> skip(np);
     std::vector<int> skipC(np);
     // encoder + bottleneck
     for (int l = 0; l <= np; ++l) {
@@ -272,7 +295,7 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
             const ConvLayer &L = net->enc[l][i];
             int inD = Di, inH = Hi, inW = Wi;
             if (L.stride == 2) { inD = Di * 2; inH = Hi * 2; inW = Wi * 2; }
-            float *out = buf((int)(i & 1), l);
+            void *out = buf((int)(i & 1), l);
             MI355_TRY(run_block(net, pl, L, cur, curC, nullptr, 0, N, inD, inH, inW, out, s));
             cur = out; curC = L.cout;
         }
@@ -282,22 +305,25 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
     for (int u = 0; u < np; ++u) {
         const int l = np - 1 - u;
         const int Dl = D >> l, Hl = H >> l, Wl = W >> l;
-        float *up = buf(2, l);
-        MI355_REQUIRE(net->tu[u].cin == curC, "tu.%d expects %d channels, got %d", u, net->tu[u].cin, curC);
+        void *up = buf(2, l);
+        const int tcin = f16 ? net->tuh[u].cin : net->tu[u].cin, tcout = f16 ? net->tuh[u].cout : net->tu[u].cout;
+        MI355_REQUIRE(tcin == curC, "tu.%d expects %d channels, got %d", u, tcin, curC);
         {
+            const double es = f16 ? 2.0 : 4.0;
             const double vin = (double)N * (Dl / 2) * (Hl / 2) * (Wl / 2);
-            ProfScope ps(net, s, "tconv2_f32_mfma_kernel<2>", 2.0 * vin * net->tu[u].cin * net->tu[u].cout * 8.0,
-                         4.0 * (vin * net->tu[u].cin + 8.0 * vin * net->tu[u].cout + 8.0 * net->tu[u].cin * net->tu[u].cout));
-            MI355_TRY(tconv2_mfma_f32(net->tu[u], cur, N, Dl / 2, Hl / 2, Wl / 2, up, s));
+            ProfScope ps(net, s, f16 ? "tconv2_f16_mfma_kernel<2>" : "tconv2_f32_mfma_kernel<2>", 2.0 * vin * tcin * tcout * 8.0,
+                         es * (vin * tcin + 8.0 * vin * tcout + 8.0 * tcin * tcout));
+            if (f16) MI355_TRY(tconv2_mfma_f16(net->tuh[u], (const _Float16 *)cur, N, Dl / 2, Hl / 2, Wl / 2, (_Float16 *)up, s));
+            else MI355_TRY(tconv2_mfma_f32(net->tu[u], (const float *)cur, N, Dl / 2, Hl / 2, Wl / 2, (float *)up, s));
         }
         // concat order (upsampled, skip): generic_UNet.py:438 - never materialised
-        const float *in0 = up, *in1 = skip[l];
-        int C0 = net->tu[u].cout, C1 = skipC[l];
+        const void *in0 = up, *in1 = skip[l];
+        int C0 = tcout, C1 = skipC[l];
         // outputs alternate between T and whichever of A/B is not the skip
-        float *freeAB = (skip[l] == buf(0, l)) ? buf(1, l) : buf(0, l);
+        void *freeAB = (skip[l] == buf(0, l)) ? buf(1, l) : buf(0, l);
         for (size_t i = 0; i < net->dec[u].size(); ++i) {
             const ConvLayer &L = net->dec[u][i];
-            float *out = (i & 1) ? freeAB : buf(3, l);
+            void *out = (i & 1) ? freeAB : buf(3, l);
             MI355_TRY(run_block(net, pl, L, in0, C0, in1, C1, N, Dl, Hl, Wl, out, s));
             in0 = out; C0 = L.cout; in1 = nullptr; C1 = 0;
         }
@@ -423,20 +449,20 @@ static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X,
             }
         {
         const double pv = (double)samples.size() * g.P[0] * g.P[1] * g.P[2];
-        ProfScope ps(net, s, "extract_tiles_kernel", 0.0, 4.0 * pv * (net->in_channels + net->cin_pad));
+        ProfScope ps(net, s, "extract_tiles_kernel", 0.0, pv * (4.0 * net->in_channels + (net->dtype == MI355_F16 ? 2.0 : 4.0) * net->cin_pad));
         MI355_TRY(extract_tiles(vol, net->in_channels, Z, Y, X, g.pad_lo[0], g.pad_lo[1], g.pad_lo[2], samples.data(),
                                 (int)samples.size(), g.P[0], g.P[1], g.P[2], net->cin_pad,
-                                (float *)(net->arena + pl.x0_off), s));
+                                (void *)(net->arena + pl.x0_off), net->dtype, s));
         }
-        const float *feat; int fc;
+        const void *feat; int fc;
         MI355_TRY(forward_features(net, pl, (int)samples.size(), g.P[0], g.P[1], g.P[2], &feat, &fc, s));
         MI355_REQUIRE(fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
         for (int i = 0; i < nb; ++i) {
             const TileDesc &td = g.tiles[mine[b0 + i]];
             const double pv = (double)g.P[0] * g.P[1] * g.P[2];
             ProfScope ps(net, s, "head_aggregate_kernel", 2.0 * pv * nm * fc * net->num_classes,
-                         4.0 * pv * (nm * fc + 2.0 * net->num_classes + 3.0));
-            MI355_TRY(head_aggregate(net->head, feat, i * nm, g.mirrors.data(), nm, g.P[0], g.P[1], g.P[2], o.nonlin,
+                         pv * ((net->dtype == MI355_F16 ? 2.0 : 4.0) * nm * fc + 4.0 * (2.0 * net->num_classes + 3.0)));
+            MI355_TRY(head_aggregate(net->head, feat, net->dtype, i * nm, g.mirrors.data(), nm, g.P[0], g.P[1], g.P[2], o.nonlin,
                                      use_gauss ? net->gauss_dev : nullptr, agg, (cnt && world == 1) ? cnt : nullptr,
                                      g.Zp[0], g.Zp[1], g.Zp[2], td.z0, td.y0, td.x0, s));
         }
@@ -458,12 +484,12 @@ extern "C" int mi355_device_count(void) {
 extern "C" int mi355_unet_create(const mi355_unet_desc *d, mi355_unet_t *out) {
     MI355_REQUIRE(d && out, "null argument");
     MI355_TRY(require_device());
-    MI355_REQUIRE(d->dtype == MI355_F32, "dtype %d: only MI355_F32 is built in this version", d->dtype);
+    MI355_REQUIRE(d->dtype == MI355_F32 || d->dtype == MI355_F16, "dtype %d unknown", d->dtype);
     MI355_REQUIRE(d->num_pool >= 1 && d->num_pool <= 7, "num_pool %d out of range", d->num_pool);
     MI355_REQUIRE(d->in_channels >= 1 && d->in_channels <= 8, "in_channels %d unsupported (1..8)", d->in_channels);
     MI355_REQUIRE(d->norm >= MI355_NORM_NONE && d->norm <= MI355_NORM_GROUP, "norm kind %d", d->norm);
     mi355_unet *net = new mi355_unet();
-    net->in_channels = d->in_channels; net->cin_pad = 8; net->num_classes = d->num_classes;
+    net->in_channels = d->in_channels; net->cin_pad = d->dtype == MI355_F16 ? 16 : 8; net->num_classes = d->num_classes;
     net->num_pool = d->num_pool; net->norm = d->norm; net->num_groups = d->num_groups;
     net->nonlin_first = d->nonlin_first; net->dtype = d->dtype; net->eps = d->eps; net->slope = d->lrelu_slope;
     int rc = MI355_OK;
@@ -471,7 +497,7 @@ extern "C" int mi355_unet_create(const mi355_unet_desc *d, mi355_unet_t *out) {
     int prevC = net->cin_pad;
     net->enc.resize(d->num_pool + 1);
     net->dec.resize(d->num_pool);
-    net->tu.resize(d->num_pool);
+    if (d->dtype == MI355_F16) net->tuh.resize(d->num_pool); else net->tu.resize(d->num_pool);
     std::vector<int> skipC(d->num_pool, 0);
     auto fail = [&](int code) { destroy(net); return code; };
     for (int l = 0; l <= d->num_pool && rc == MI355_OK; ++l) {
@@ -496,7 +522,8 @@ extern "C" int mi355_unet_create(const mi355_unet_desc *d, mi355_unet_t *out) {
         const int l = d->num_pool - 1 - u;
         const mi355_tconv_desc &td = d->tconvs[u];
         if (td.cin != prevC) { set_error("tu.%d: cin %d, expected %d", u, td.cin, prevC); return fail(MI355_ERR_INVALID); }
-        rc = tconv_weights_upload(td.weight, td.cin, td.cout, &net->tu[u]);
+        rc = d->dtype == MI355_F16 ? tconv_weights_upload_f16(td.weight, td.cin, td.cout, &net->tuh[u])
+                                   : tconv_weights_upload(td.weight, td.cin, td.cout, &net->tu[u]);
         if (rc != MI355_OK) return fail(rc);
         net->max_channels = std::max(net->max_channels, td.cout);
         int inC = td.cout + skipC[l];
@@ -536,7 +563,7 @@ extern "C" int64_t mi355_unet_flops(mi355_unet_t net, int d, int h, int w) {
         for (auto &L : net->enc[l]) total += 2 * vox(l) * L.cout * L.cin * 27;
     for (int u = 0; u < np; ++u) {
         const int l = np - 1 - u;
-        total += 2 * vox(l + 1) * net->tu[u].cin * net->tu[u].cout * 8;
+        total += 2 * vox(l + 1) * (net->dtype == MI355_F16 ? (int64_t)net->tuh[u].cin * net->tuh[u].cout : (int64_t)net->tu[u].cin * net->tu[u].cout) * 8;
         for (auto &L : net->dec[u]) total += 2 * vox(l) * L.cout * L.cin * 27;
     }
     total += 2 * vox(0) * net->head.cin * net->head.ncls;
@@ -551,11 +578,11 @@ extern "C" int mi355_unet_forward(mi355_unet_t net, const float *x_dev, int n, i
     MI355_TRY(make_plan(*net, n, d, h, w, &pl));
     MI355_TRY(ensure_arena(net, pl.total));
     const int64_t V = (int64_t)d * h * w;
-    MI355_TRY(nchw_to_ndhwc(x_dev, n, net->in_channels, V, net->cin_pad, (float *)(net->arena + pl.x0_off), s));
-    const float *feat; int fc;
+    MI355_TRY(nchw_to_ndhwc(x_dev, n, net->in_channels, V, net->cin_pad, (void *)(net->arena + pl.x0_off), net->dtype, s));
+    const void *feat; int fc;
     MI355_TRY(forward_features(net, pl, n, d, h, w, &feat, &fc, s));
     MI355_REQUIRE(fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
-    MI355_TRY(head_logits(net->head, feat, n, V, logits_dev, s));
+    MI355_TRY(head_logits(net->head, feat, net->dtype, n, V, logits_dev, s));
     return MI355_OK;
 }
 
@@ -677,6 +704,34 @@ extern "C" int mi355_tconv3d_ndhwc(const float *x_dev, int n, int d, int h, int 
     int rc = tconv2_mfma_f32(tw, x_dev, n, d, h, w, y_dev, (hipStream_t)stream);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     tconv_weights_free(&tw);
+    if (rc == MI355_OK && e != hipSuccess) { set_error("tconv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
+    return rc;
+}
+
+extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
+                                      const float *bias_host, int cout, int stride, int act, float slope, void *y_dev,
+                                      void *stream) {
+    MI355_TRY(require_device());
+    ConvWeightsH cw;
+    MI355_TRY(conv_weights_upload_f16(weight_host, bias_host, cin, cin, cout, stride, &cw));
+    ConvCallH c;
+    c.in0 = (const _Float16 *)x_dev; c.C0 = cin; c.N = n; c.Di = d; c.Hi = h; c.Wi = w; c.out = (_Float16 *)y_dev;
+    c.act = act; c.slope = slope;
+    int rc = conv3d_mfma_f16(cw, c, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    conv_weights_free_f16(&cw);
+    if (rc == MI355_OK && e != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
+    return rc;
+}
+
+extern "C" int mi355_tconv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
+                                       int cout, void *y_dev, void *stream) {
+    MI355_TRY(require_device());
+    TConvWeightsH tw;
+    MI355_TRY(tconv_weights_upload_f16(weight_host, cin, cout, &tw));
+    int rc = tconv2_mfma_f16(tw, (const _Float16 *)x_dev, n, d, h, w, (_Float16 *)y_dev, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    tconv_weights_free_f16(&tw);
     if (rc == MI355_OK && e != hipSuccess) { set_error("tconv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
     return rc;
 }

@@ -80,8 +80,19 @@ def zscore_masked_(vol, mask):
 
 
 def conv3d_ndhwc(x, weight, bias=None, stride=1, act=0, slope=0.01, impl="mfma"):
-    """Single conv (test entry point). x: CUDA fp32 [N,D,H,W,Cin]; weight: numpy [Cout,Cin,3,3,3]."""
+    """Single conv (test entry point). x: CUDA fp32 or fp16 [N,D,H,W,Cin]; weight: numpy [Cout,Cin,3,3,3]."""
     import torch
+    if x.dtype == torch.float16:
+        x = _require_cuda(x, torch.float16, "x")
+        n, d, h, w, cin = x.shape
+        weight = np.ascontiguousarray(weight, dtype=np.float32)
+        cout = weight.shape[0]
+        b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+        do, ho, wo = (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1
+        y = torch.empty((n, do, ho, wo, cout), dtype=torch.float16, device=x.device)
+        _lib.check(_lib.load().mi355_conv3d_ndhwc_f16(x.data_ptr(), n, d, h, w, cin, _lib.fptr(weight), _lib.fptr(b), cout,
+                                                      stride, act, slope, y.data_ptr(), _stream(x)), "mi355_conv3d_ndhwc_f16")
+        return y
     x = _require_cuda(x, torch.float32, "x")
     n, d, h, w, cin = x.shape
     weight = np.ascontiguousarray(weight, dtype=np.float32)
@@ -98,6 +109,15 @@ def conv3d_ndhwc(x, weight, bias=None, stride=1, act=0, slope=0.01, impl="mfma")
 def tconv3d_ndhwc(x, weight):
     """Single ConvTranspose3d k=2 s=2 (test entry point). weight: numpy [Cin,Cout,2,2,2]."""
     import torch
+    if x.dtype == torch.float16:
+        x = _require_cuda(x, torch.float16, "x")
+        n, d, h, w, cin = x.shape
+        weight = np.ascontiguousarray(weight, dtype=np.float32)
+        cout = weight.shape[1]
+        y = torch.empty((n, 2 * d, 2 * h, 2 * w, cout), dtype=torch.float16, device=x.device)
+        _lib.check(_lib.load().mi355_tconv3d_ndhwc_f16(x.data_ptr(), n, d, h, w, cin, _lib.fptr(weight), cout, y.data_ptr(),
+                                                       _stream(x)), "mi355_tconv3d_ndhwc_f16")
+        return y
     x = _require_cuda(x, torch.float32, "x")
     n, d, h, w, cin = x.shape
     weight = np.ascontiguousarray(weight, dtype=np.float32)

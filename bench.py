@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, same guide
 PEAK_HBM_GBS = 8000.0
 
 
@@ -36,6 +37,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="BASELINE.json config (1-based)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-tiles", type=int, default=0)
+    ap.add_argument("--dtype", choices=("f32", "f16"), default=None, help="default: f32 for config 2, f16 for config 3")
     args = ap.parse_args()
 
     import torch
@@ -58,6 +60,7 @@ def main():
 
     # ---- workload
     patch = (128, 128, 128)
+    dtype = args.dtype or ("f32" if args.config == 2 else "f16")
     if args.config == 2:
         models = [("A", 7)]
         do_mirroring = False
@@ -65,11 +68,11 @@ def main():
     else:
         models = [("A", 7), ("B", 8)]
         do_mirroring = True
-        workload = "BASELINE.json configs[2] at fp32: 1 volume, 8-way mirror TTA, models A+B, 1 fold each, label ensemble"
+        workload = "BASELINE.json configs[2]: 1 volume, 8-way mirror TTA, models A+B, 1 fold each, label-round ensemble"
     nets = []
     for name, seed in models:
         sd, meta = synthetic.make_model(name, seed=seed)
-        nets.append(brats_amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"]))
+        nets.append(brats_amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"], dtype=dtype))
         del sd
     raw = synthetic.make_volume(seed=1000 + rank)
     data, props = preprocessing.preprocess_case(raw, device)
@@ -133,8 +136,9 @@ def main():
             traffic = json.load(open(pmc_file)).get(dom_name, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved_tflops, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                    unit="TFLOP/s", frac=round(achieved_tflops / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_F16_MFMA_TFLOPS
+    roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved_tflops, 2), peak=peak,
+                    unit="TFLOP/s", frac=round(achieved_tflops / peak, 4), traffic=traffic,
                     launches=dom["launches"], avg_launch_ms=round(avg_ms, 4),
                     algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3),
                     algorithmic_mb_per_launch=round(dom["bytes"] / dom["launches"] / 1e6, 2),
@@ -171,7 +175,7 @@ def main():
         "metric": "BraTS volumes/sec (4-modality 240x240x155)", "value": round(value, 4), "unit": "volumes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": workload, "patch": list(patch), "tiles_per_volume": n_tiles, "mirrors": n_mirrors,
                    "models": [m[0] for m in models], "crop": list(data.shape[1:]), "sharding": "cases (one volume per rank per step)",
                    "tflop_per_volume": round(flops_per_volume / 1e12, 3)},

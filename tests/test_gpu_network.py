@@ -119,3 +119,58 @@ def test_fold_mean_and_tile_sharding(amd, gpu):
     assert np.abs(probs - per_fold[0]).max() <= PROB_TOL
     for r in range(1, world):
         assert torch.equal(parts[r][1], parts[0][1])  # every rank holds the same normaliser
+
+
+# --------------------------------------------------------------------------- fp16 storage (BASELINE configs[2])
+# Tolerance for the fp16 path, stated here as the north_star asks: activations are rounded to fp16
+# (2^-11 relative) after every block, accumulation stays fp32.  Against the fp32 CPU oracle we require
+# logits within 3 % of their spread, probabilities within 5e-2, Dice >= 0.995 on all voxels and
+# >= 0.999 on the voxels whose reference logit is not within 1.0 of the decision threshold
+# (measured: 0.5 % of the spread for BatchNorm-folded nets, 2.3 % with run-time Instance/GroupNorm,
+# which rounds twice per block).
+def _check_logits_f16(got, ref):
+    spread = float(ref.std())
+    err = float(np.abs(got - ref).max())
+    assert err <= 3e-2 * max(spread, 1.0), f"fp16 logit max abs err {err} (spread {spread})"
+    pg = 1 / (1 + np.exp(-got.astype(np.float64)))
+    pr = 1 / (1 + np.exp(-ref.astype(np.float64)))
+    assert float(np.abs(pg - pr).max()) <= 5e-2
+    lg, lr = tiler_ref.regions_to_labels(pg[0].astype(np.float32)), tiler_ref.regions_to_labels(pr[0].astype(np.float32))
+    assert tiler_ref.brats_region_dice(lg, lr)["mean"] >= 0.995
+    sure = (np.abs(ref[0]) >= 1.0).all(0)
+    assert tiler_ref.brats_region_dice(lg[sure], lr[sure])["mean"] >= 0.999
+    return err / spread
+
+
+@pytest.mark.parametrize("name", ["A", "A_in", "B"])
+def test_forward_f16_64_matches_oracle(amd, gpu, name):
+    sd, meta = amd.synthetic.make_model(name, seed=7)
+    net = amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"], dtype="f16")
+    x = np.random.RandomState(1).standard_normal((1, 4, 64, 64, 64)).astype(np.float32)
+    ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])).numpy()
+    got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
+    rel = _check_logits_f16(got, ref)
+    print(f"fp16 {name}: max logit err / spread = {rel:.2e}")
+    net.close()
+
+
+def test_forward_f16_batch_ragged_and_simple_kernel(amd, gpu, monkeypatch):
+    sd, meta = amd.synthetic.make_model("A_in", seed=3, num_pool=3, max_feat=128)
+    x = np.random.RandomState(4).standard_normal((3, 4, 32, 64, 96)).astype(np.float32)
+    ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm="instance")).numpy()
+    net = amd.UNet(sd, norm="instance", dtype="f16")
+    got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
+    for n in range(3):
+        _check_logits_f16(got[n:n + 1], ref[n:n + 1])
+
+
+def test_sliding_window_f16_tta(amd, gpu):
+    sd = _small_net(amd)
+    net = amd.UNet(sd, norm="batch", dtype="f16")
+    patch = (32, 32, 32)
+    vol = np.random.RandomState(31).standard_normal((4, 40, 56, 44)).astype(np.float32)
+    ref = tiler_ref.predict_3d_tiled(tiler_ref.make_net_fn(sd, unet_ref.default_cfg("batch")), vol, patch, 3)
+    got = amd.predictor.predict_folds([net], vol, patch).cpu().numpy()
+    assert np.abs(got - ref).max() <= 5e-2
+    d = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(got), tiler_ref.regions_to_labels(ref))
+    assert d["mean"] >= 0.995

@@ -134,3 +134,58 @@ def test_compute_steps_table(amd):
     assert amd.ops.compute_steps(128, 140, 0.5) == [0, 12]
     assert amd.ops.compute_steps(128, 240, 0.5) == [0, 56, 112]
     assert amd.ops.compute_steps(128, 128, 0.5) == [0]
+
+
+# --------------------------------------------------------------------------- fp16 storage kernels
+F16_CONV_CASES = [
+    (1, 8, 8, 32, 32, 32, 1, 0),
+    (2, 8, 12, 40, 16, 64, 1, 1),
+    (1, 16, 16, 32, 32, 64, 2, 0),
+    (2, 10, 6, 14, 64, 32, 2, 1),
+    (1, 32, 32, 32, 64, 64, 1, 0),
+    (8, 16, 16, 32, 32, 32, 1, 1),   # enough tiles for the 512-voxel (MF=4) pipelined variant
+]
+
+
+@pytest.mark.parametrize("case", F16_CONV_CASES)
+def test_conv3d_f16_matches_torch(amd, gpu, case):
+    """fp16 inputs/weights, fp32 accumulate: compared with fp32 torch on the SAME fp16-rounded operands,
+    so the only differences are summation order and the final rounding of the output to fp16."""
+    n, d, h, w, cin, cout, stride, act = case
+    rs = np.random.RandomState(17)
+    x = _rand(rs, n, d, h, w, cin).astype(np.float16)
+    wt = (_rand(rs, cout, cin, 3, 3, 3) / np.sqrt(cin * 27)).astype(np.float16)
+    b = _rand(rs, cout)
+    ref = _ref_conv(x.astype(np.float32), wt.astype(np.float32), b, stride, act, 0.01)
+    y = amd.ops.conv3d_ndhwc(torch.from_numpy(x).to(gpu), wt.astype(np.float32), b, stride=stride, act=act, slope=0.01)
+    y = y.float().cpu().numpy()
+    assert y.shape == ref.shape
+    err = np.abs(y - ref).max()
+    assert err <= 2e-3 * max(1.0, np.abs(ref).max()), f"max abs err {err}"
+
+
+def test_conv3d_f16_identity_asymmetric(amd, gpu):
+    rs = np.random.RandomState(3)
+    x = rs.randint(-8, 9, size=(1, 8, 8, 32, 32)).astype(np.float16)
+    wt = np.zeros((32, 32, 3, 3, 3), np.float32)
+    for c in range(32):
+        wt[(3 * c + 1) % 32, c, 1, 1, 1] = float(c % 7 + 1)
+    y = amd.ops.conv3d_ndhwc(torch.from_numpy(x).to(gpu), wt, None).float().cpu().numpy()
+    ref = np.zeros_like(y)
+    for c in range(32):
+        ref[..., (3 * c + 1) % 32] = x[..., c].astype(np.float32) * (c % 7 + 1)
+    assert np.array_equal(y, ref)
+
+
+@pytest.mark.parametrize("case", [(1, 4, 4, 4, 32, 32), (2, 3, 5, 6, 64, 32), (1, 2, 2, 2, 256, 512)])
+def test_tconv_f16_matches_torch(amd, gpu, case):
+    n, d, h, w, cin, cout = case
+    rs = np.random.RandomState(5)
+    x = _rand(rs, n, d, h, w, cin).astype(np.float16)
+    wt = (_rand(rs, cin, cout, 2, 2, 2) / np.sqrt(cin)).astype(np.float16)
+    ref = F.conv_transpose3d(torch.from_numpy(x.astype(np.float32)).permute(0, 4, 1, 2, 3),
+                             torch.from_numpy(wt.astype(np.float32)), None, stride=2)
+    ref = ref.permute(0, 2, 3, 4, 1).contiguous().numpy()
+    y = amd.ops.tconv3d_ndhwc(torch.from_numpy(x).to(gpu), wt.astype(np.float32)).float().cpu().numpy()
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
