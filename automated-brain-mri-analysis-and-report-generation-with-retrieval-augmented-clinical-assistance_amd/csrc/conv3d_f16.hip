@@ -198,13 +198,15 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
 }
 
 // ------------------------------------------------------------------ pipelined persistent kernel (stride 1)
-template <int MF, int NF>
+// ABL (timing experiments only, MI355_CONV_ABLATE): 1 = no voxel-fragment LDS reads, 2 = no weight fetches,
+// 4 = no staging of the next brick (results are then wrong; only the clock matters).
+template <int MF, int NF, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     constexpr int SLOTS = MF == 4 ? 11 : 8;  // 16-B staging pieces per thread and chunk
     constexpr int BD = 3;                    // weight fragments fetched BD tap-steps ahead; the ring phase must
                                              // be the same in every chunk, so BD divides 27
-    constexpr int FLIGHT = 12;               // tap-steps between a staging fetch and its LDS write
+    constexpr int FLIGHT = 10;               // tap-steps between a staging fetch and its LDS write
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
     const int IX = p.IX, IY = p.IY;
@@ -242,20 +244,29 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         tc.oz0 = tile_z << p.lz; tc.oy0 = tile_y << p.ly; tc.ox0 = tile_x << p.lx;
         return tc;
     };
-    auto stage_issue = [&](const TileCoord &tc, int ch, int r, int &dst, bool &inside) {
-        const int cglob = ch * 16;
-        const half_t *src; int Csrc, coff;
-        if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
-        else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
+    // Tile-invariant part of every staging slot, computed once: brick coordinates packed 10 bits each
+    // (bz | by<<10 | bx<<20, or -1 for an unused slot) - the per-chunk work is then 3 adds, 3 compares, one mad.
+    int st_pack[SLOTS];
+#pragma unroll
+    for (int r = 0; r < SLOTS; ++r) {
         const int i = r * 256 + tid;
         const int bv = i >> 1;
         const int rr = (int)fdiv((uint32_t)bv, p.div_IX);
         const int bx = bv - rr * IX;
         const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
         const int by = rr - bz * IY;
-        const int iz = tc.oz0 - 1 + bz, iy = tc.oy0 - 1 + by, ix = tc.ox0 - 1 + bx;
-        dst = (i < npieces) ? (i & 1) * p.plane_bytes + bv * 16 : -1;
-        inside = (i < npieces) && ((unsigned)iz < (unsigned)p.Di) && ((unsigned)iy < (unsigned)p.Hi) &&
+        st_pack[r] = (i < npieces) ? (bz | (by << 10) | (bx << 20)) : -1;
+    }
+    auto stage_issue = [&](const TileCoord &tc, int ch, int r, int &dst, bool &inside) {
+        const int cglob = ch * 16;
+        const half_t *src; int Csrc, coff;
+        if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
+        else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
+        const int pk = st_pack[r];
+        const int i = r * 256 + tid;
+        const int iz = tc.oz0 - 1 + (pk & 1023), iy = tc.oy0 - 1 + ((pk >> 10) & 1023), ix = tc.ox0 - 1 + ((pk >> 20) & 1023);
+        dst = (pk >= 0) ? (i & 1) * p.plane_bytes + (i >> 1) * 16 : -1;
+        inside = (pk >= 0) && ((unsigned)iz < (unsigned)p.Di) && ((unsigned)iy < (unsigned)p.Hi) &&
                  ((unsigned)ix < (unsigned)p.Wi);
         size_t off = ((((size_t)tc.n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * Csrc + coff + qoff;
         off = inside ? off : 0;
@@ -270,7 +281,9 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
 
-    const half_t *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512) + lane * 8;
+    // wave-uniform weight base (SGPRs) + a 32-bit per-lane offset: the tap / chunk offsets are scalar arithmetic
+    const half_t *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512);
+    const int wlane = lane * 8;
     const int co_blk = (int)blockIdx.y * NF * 32;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
     for (int k = 0; k < BD; ++k)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) bq[k][nf] = *(const f16x8 *)(wblk + (size_t)k * (NF * 512) + nf * 512);
+        for (int nf = 0; nf < NF; ++nf) bq[k][nf] = *(const f16x8 *)(wblk + (size_t)k * (NF * 512) + nf * 512 + wlane);
     __syncthreads();
 
     int ch = 0, buf = 0;
@@ -309,29 +322,36 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
+            // ---- all memory instructions of the step first (next step's voxel fragments, the weight fragment
+            // BD steps ahead, one staging fetch), pinned ahead of the MFMAs so that every fragment has a full
+            // step of MFMA time to arrive (the compiler otherwise sinks the LDS reads to just before their use)
+            f16x8 bnew[NF];
             if (tap + 1 < 27) {
                 const int nt = tap + 1;
                 const int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
                 const int off = ((dz * IY + dy) * IX + dx) * 16;
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf) a[(tap + 1) & 1][mf] = *(const f16x8 *)(bufc + a_base[mf] + off);
+                for (int mf = 0; mf < MF; ++mf) a[(tap + 1) & 1][mf] = (ABL & 1) ? a[tap & 1][mf] : *(const f16x8 *)(bufc + a_base[mf] + off);
             }
+            {
+                const int k = tap + BD;
+                const half_t *wsrc = (k < 27) ? wch + (size_t)k * (NF * 512) : wnx + (size_t)(k - 27) * (NF * 512);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) bnew[nf] = (ABL & 2) ? bq[tap % BD][nf] : *(const f16x8 *)(wsrc + nf * 512 + wlane);
+            }
+            if (!(ABL & 4) && tap < SLOTS) st_v[tap] = stage_issue(nxt, nch_eff, tap, st_dst[tap], st_in[tap]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf)
                     acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[tap % BD][nf], a[tap & 1][mf], acc[mf][nf], 0, 0, 0);
-            {
-                const int k = tap + BD;
-                const half_t *wsrc = (k < 27) ? wch + (size_t)k * (NF * 512) : wnx + (size_t)(k - 27) * (NF * 512);
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf) bq[tap % BD][nf] = *(const f16x8 *)(wsrc + nf * 512);
-            }
-            if (tap < SLOTS) st_v[tap] = stage_issue(nxt, nch_eff, tap, st_dst[tap], st_in[tap]);
+            for (int nf = 0; nf < NF; ++nf) bq[tap % BD][nf] = bnew[nf];
 #pragma unroll
             for (int r = 0; r < SLOTS; ++r) {
                 const int wr = r + FLIGHT < 26 ? r + FLIGHT : 26;
-                if (wr == tap && have_next && st_dst[r] >= 0) *(f32x4 *)(bufn + st_dst[r]) = st_in[r] ? st_v[r] : zero4;
+                if (!(ABL & 4) && wr == tap && have_next && st_dst[r] >= 0) *(f32x4 *)(bufn + st_dst[r]) = st_in[r] ? st_v[r] : zero4;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -474,6 +494,13 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         if (gx > need) gx = need;
         dim3 grid(gx, gy);
         if (kernel_name) *kernel_name = w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<*, 1>" : "conv3_f16_mfma_pipe_kernel<*, 2>";
+        static int abl = -1;
+        if (abl < 0) { const char *e = getenv("MI355_CONV_ABLATE"); abl = e ? atoi(e) : 0; }
+        if (MF == 4 && abl == 1) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 1>, a, grid, lds_bytes, s, &attr[7]);
+        if (MF == 4 && abl == 2) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 2>, a, grid, lds_bytes, s, &attr[7]);
+        if (MF == 4 && abl == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 4>, a, grid, lds_bytes, s, &attr[7]);
+        if (MF == 4 && abl == 7) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 7>, a, grid, lds_bytes, s, &attr[7]);
+        if (MF == 4 && abl == 6) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 6>, a, grid, lds_bytes, s, &attr[7]);
         if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1>, a, grid, lds_bytes, s, &attr[0]);
         if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1>, a, grid, lds_bytes, s, &attr[1]);
         return launch_h(conv3_f16_mfma_pipe_kernel<2, 2>, a, grid, lds_bytes, s, &attr[2]);
