@@ -41,12 +41,52 @@ struct ConvArgsH {
 };
 
 // Epilogue shared by both kernels (C/D map of the 32x32 MFMA: col = lane&31 = voxel,
-// row = (r&3) + 8*(r>>2) + 4*(lane>>5) = cout).
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5) = cout).  The accumulators already hold the bias (acc_init_bias), so the
+// per-element work is LeakyReLU as max(x, slope*x) and the fp16 conversion; the statistics are only computed when
+// the layer needs them (Instance/GroupNorm).
+template <int MF, int NF>
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[MF][NF], const float *bias, int co_blk, int half) {
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *(const f32x4 *)(bias + co_blk + nf * 32 + 8 * g + 4 * half);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[mf][nf][4 * g + k] = b[k];
+        }
+}
+
 template <int MF, int NF>
 __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const ConvArgsH &p, int n, int oz0, int oy0,
                                                   int ox0, int co_blk, float *red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
+    const bool lrelu = p.act == ACT_LRELU;
+    const float slope = lrelu ? p.slope : 1.0f;  // max(x, 1*x) = x
+    if (!p.stats) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int v = (wave * MF + mf) * 32 + l31;
+            const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
+            const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
+            half_t *orow = p.out + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + 4 * half;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 val;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float x = acc[mf][nf][4 * g + k];
+                        val[k] = (half_t)fmaxf(x, x * slope);
+                    }
+                    if (ok) *(f16x4 *)(orow + nf * 32 + 8 * g) = val;
+                }
+        }
+        return;
+    }
     float s1[NF][16], s2[NF][16];
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
@@ -62,12 +102,11 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
         for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bias = *(const f32x4 *)(p.bias + co_blk + nf * 32 + 8 * g + 4 * half);
                 f16x4 val;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float x = acc[mf][nf][4 * g + k] + bias[k];
-                    if (p.act == ACT_LRELU) x = x > 0.f ? x : x * p.slope;
+                    float x = acc[mf][nf][4 * g + k];
+                    x = fmaxf(x, x * slope);
                     val[k] = (half_t)x;
                     if (ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
                 }
@@ -75,28 +114,26 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
             }
         }
     }
-    if (p.stats) {
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
+    for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float a = s1[nf][r], b = s2[nf][r];
+        for (int r = 0; r < 16; ++r) {
+            float a = s1[nf][r], b = s2[nf][r];
 #pragma unroll
-                for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-                if (l31 == 0) {
-                    const int c = nf * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    red[(wave * NF * 32 + c) * 2 + 0] = a;
-                    red[(wave * NF * 32 + c) * 2 + 1] = b;
-                }
+            for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+            if (l31 == 0) {
+                const int c = nf * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[(wave * NF * 32 + c) * 2 + 0] = a;
+                red[(wave * NF * 32 + c) * 2 + 1] = b;
             }
-        __syncthreads();
-        if (tid < NF * 32 * 2) {
-            const int c = tid >> 1, k = tid & 1;
-            double tot = 0.0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
-            atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, tot);
         }
+    __syncthreads();
+    if (tid < NF * 32 * 2) {
+        const int c = tid >> 1, k = tid & 1;
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
+        atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, tot);
     }
 }
 
@@ -127,12 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
         a_base[mf] = half * p.plane_bytes + ((z * STRIDE * IY + y * STRIDE) * IX + x * STRIDE) * 16;
     }
     f32x16 acc[MF][NF];
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+    acc_init_bias<MF, NF>(acc, p.bias, (int)blockIdx.y * NF * 32, half);
 
     const half_t *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512) + lane * 8;
     for (int ch = 0; ch < p.nchunks; ++ch) {
@@ -244,9 +276,11 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         tc.oz0 = tile_z << p.lz; tc.oy0 = tile_y << p.ly; tc.ox0 = tile_x << p.lx;
         return tc;
     };
-    // Tile-invariant part of every staging slot, computed once: brick coordinates packed 10 bits each
-    // (bz | by<<10 | bx<<20, or -1 for an unused slot) - the per-chunk work is then 3 adds, 3 compares, one mad.
-    int st_pack[SLOTS];
+    // Tile-invariant part of every staging slot, computed once per kernel: the element offset of the piece
+    // relative to the brick origin voxel (32-bit, per lane) and the brick faces it lies on (bit 0/1: z lo/hi,
+    // 2/3: y, 4/5: x; -1 = unused slot).  Per chunk a fetch then costs one AND, one compare, one select.
+    int st_rel[SLOTS], st_face[SLOTS];
+    const int Cs0 = p.C0;  // relative offsets are kept for in0's channel stride; in1 (concat half) rescales below
 #pragma unroll
     for (int r = 0; r < SLOTS; ++r) {
         const int i = r * 256 + tid;
@@ -255,31 +289,50 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         const int bx = bv - rr * IX;
         const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
         const int by = rr - bz * IY;
-        st_pack[r] = (i < npieces) ? (bz | (by << 10) | (bx << 20)) : -1;
+        st_rel[r] = (bz * p.Hi + by) * p.Wi + bx;   // in voxels
+        st_face[r] = (i < npieces) ? ((bz == 0) | ((bz == p.IZ - 1) << 1) | ((by == 0) << 2) | ((by == IY - 1) << 3) |
+                                      ((bx == 0) << 4) | ((bx == IX - 1) << 5))
+                                   : -1;
     }
-    auto stage_issue = [&](const TileCoord &tc, int ch, int r, int &dst, bool &inside) {
+    (void)Cs0;
+    // which faces of the brick of tile tc stick out of the volume (wave-uniform)
+    auto tile_faces = [&](const TileCoord &tc) {
+        // a brick spans [o0-1, o0+T+1): the low face is outside iff o0 == 0, the high face iff o0 + T >= dim.
+        // voxels beyond the high face + 1 (tiles overhanging a ragged volume) are caught by the exact test below.
+        return (tc.oz0 == 0) | ((tc.oz0 + (1 << p.lz) >= p.Di) << 1) | ((tc.oy0 == 0) << 2) |
+               ((tc.oy0 + (1 << p.ly) >= p.Hi) << 3) | ((tc.ox0 == 0) << 4) | ((tc.ox0 + (1 << p.lx) >= p.Wi) << 5);
+    };
+    auto tile_ragged = [&](const TileCoord &tc) {
+        return (tc.oz0 + (1 << p.lz) > p.Di) | (tc.oy0 + (1 << p.ly) > p.Hi) | (tc.ox0 + (1 << p.lx) > p.Wi);
+    };
+    auto stage_issue = [&](const TileCoord &tc, int faces, bool ragged, int ch, int r, int &dst, bool &inside) {
         const int cglob = ch * 16;
         const half_t *src; int Csrc, coff;
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
-        const int pk = st_pack[r];
         const int i = r * 256 + tid;
-        const int iz = tc.oz0 - 1 + (pk & 1023), iy = tc.oy0 - 1 + ((pk >> 10) & 1023), ix = tc.ox0 - 1 + ((pk >> 20) & 1023);
-        dst = (pk >= 0) ? (i & 1) * p.plane_bytes + (i >> 1) * 16 : -1;
-        inside = (pk >= 0) && ((unsigned)iz < (unsigned)p.Di) && ((unsigned)iy < (unsigned)p.Hi) &&
-                 ((unsigned)ix < (unsigned)p.Wi);
-        size_t off = ((((size_t)tc.n * p.Di + iz) * p.Hi + iy) * p.Wi + ix) * Csrc + coff + qoff;
-        off = inside ? off : 0;
-        return *(const f32x4 *)(src + off);
+        const int face = st_face[r];
+        dst = (face >= 0) ? (i & 1) * p.plane_bytes + (i >> 1) * 16 : -1;
+        inside = (face >= 0) && ((face & faces) == 0);
+        if (ragged) {  // rare: tile overhangs the volume by more than the halo -> exact per-axis test
+            const int bv = i >> 1;
+            const int rr = (int)fdiv((uint32_t)bv, p.div_IX);
+            const int bx = bv - rr * IX;
+            const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
+            const int by = rr - bz * IY;
+            inside = (face >= 0) && ((unsigned)(tc.oz0 - 1 + bz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + by) < (unsigned)p.Hi) &&
+                     ((unsigned)(tc.ox0 - 1 + bx) < (unsigned)p.Wi);
+        }
+        // wave-uniform base of the brick origin voxel (may lie one voxel outside the tensor: only used when inside)
+        const long base_vox = (((long)tc.n * p.Di + (tc.oz0 - 1)) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1);
+        const half_t *sbase = src + base_vox * Csrc + coff;
+        const int rel = inside ? st_rel[r] * Csrc + qoff : 0;
+        const half_t *ptr = inside ? sbase + rel : src;
+        return *(const f32x4 *)ptr;
     };
 
     f32x16 acc[MF][NF];
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+    acc_init_bias<MF, NF>(acc, p.bias, (int)blockIdx.y * NF * 32, half);
 
     // wave-uniform weight base (SGPRs) + a 32-bit per-lane offset: the tap / chunk offsets are scalar arithmetic
     const half_t *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512);
@@ -291,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
     for (int r = 0; r < SLOTS; ++r) {
         bool inside; int dst;
-        const f32x4 v = stage_issue(cur, 0, r, dst, inside);
+        const f32x4 v = stage_issue(cur, tile_faces(cur), tile_ragged(cur), 0, r, dst, inside);
         if (dst >= 0) *(f32x4 *)(lds_raw + dst) = inside ? v : zero4;
     }
     f16x8 bq[BD][NF];
@@ -308,6 +361,8 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         const bool have_next = ntile < hi;
         const TileCoord nxt = (nch == 0 && have_next) ? decode(ntile) : cur;
         const int nch_eff = have_next ? nch : ch;
+        const int nfaces = tile_faces(nxt);
+        const bool nragged = tile_ragged(nxt);
         const char *bufc = lds_raw + buf * buf_bytes;
         char *bufn = lds_raw + (buf ^ 1) * buf_bytes;
         const half_t *wch = wblk + (size_t)ch * (27 * NF * 512);
@@ -339,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) bnew[nf] = (ABL & 2) ? bq[tap % BD][nf] : *(const f16x8 *)(wsrc + nf * 512 + wlane);
             }
-            if (!(ABL & 4) && tap < SLOTS) st_v[tap] = stage_issue(nxt, nch_eff, tap, st_dst[tap], st_in[tap]);
+            if (!(ABL & 4) && tap < SLOTS) st_v[tap] = stage_issue(nxt, nfaces, nragged, nch_eff, tap, st_dst[tap], st_in[tap]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
@@ -359,12 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 
         if (ch == p.nchunks - 1) {
             conv_epilogue_f16<MF, NF>(acc, p, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red);
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+            acc_init_bias<MF, NF>(acc, p.bias, co_blk, half);
         }
         if (!have_next) break;
         tile = ntile; ch = nch; cur = nxt; buf ^= 1;
