@@ -200,53 +200,41 @@ void head_weights_free(HeadWeights *w) {
 
 constexpr int HEAD_MAX_CLS = 8;
 
-// 8 lanes cooperate on one voxel: each takes every 8th 16-B channel quad, partial dot products
-// are combined with three xor-shuffles.  Returns the logits in every lane of the group.
+// One thread per voxel: the whole channel vector of the voxel is read with 16-B loads (every byte of every
+// line is used, consecutive lanes = consecutive voxels), the ncls x C head weights are wave-uniform (scalar loads),
+// no cross-lane traffic.  The aggregate / normaliser read-modify-writes are then fully coalesced along x.
 template <typename T>
-__device__ __forceinline__ void head_dot(const T *feat_vox, const float *w, const float *b, int C,
-                                         int ncls, int q, float *logit) {
-    float part[HEAD_MAX_CLS];
+__device__ __forceinline__ void head_dot(const T *feat_vox, const float *__restrict__ w, const float *__restrict__ b,
+                                         int C, int ncls, float *logit) {
 #pragma unroll
-    for (int k = 0; k < HEAD_MAX_CLS; ++k) part[k] = 0.f;
-    for (int c4 = q; c4 * 4 < C; c4 += 8) {
-        const f32x4 f = load4<T>(feat_vox + c4 * 4);
+    for (int k = 0; k < HEAD_MAX_CLS; ++k) logit[k] = (k < ncls) ? b[k] : 0.f;
+    for (int c = 0; c < C; c += 4) {
+        const f32x4 f = load4<T>(feat_vox + c);
 #pragma unroll
         for (int k = 0; k < HEAD_MAX_CLS; ++k)
             if (k < ncls) {
-                const f32x4 wk = *(const f32x4 *)(w + k * C + c4 * 4);
-                part[k] += f[0] * wk[0] + f[1] * wk[1] + f[2] * wk[2] + f[3] * wk[3];
+                const float *wk = w + k * C + c;
+                logit[k] = fmaf(f[0], wk[0], fmaf(f[1], wk[1], fmaf(f[2], wk[2], fmaf(f[3], wk[3], logit[k]))));
             }
-    }
-#pragma unroll
-    for (int k = 0; k < HEAD_MAX_CLS; ++k) {
-        float v = part[k];
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        logit[k] = v + (k < ncls ? b[k] : 0.f);
     }
 }
 
 template <typename T>
 __global__ void head_logits_kernel(const T *feat, const float *w, const float *b, int C, int ncls,
                                    int64_t V, int64_t total, float *logits) {
-    const int q = threadIdx.x & 7;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < total;
-         i += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float lg[HEAD_MAX_CLS];
-        head_dot<T>(feat + i * C, w, b, C, ncls, q, lg);
+        head_dot<T>(feat + i * C, w, b, C, ncls, lg);
         const int64_t n = i / V, v = i - n * V;
 #pragma unroll
         for (int k = 0; k < HEAD_MAX_CLS; ++k)
-            if (k == q && k < ncls)
-                logits[(n * ncls + k) * V + v] = lg[k];
+            if (k < ncls) logits[(n * ncls + k) * V + v] = lg[k];
     }
 }
 
 int head_logits(const HeadWeights &w, const void *feat, int dtype, int N, int64_t V, float *logits, hipStream_t s) {
     const int64_t total = (int64_t)N * V;
-    MI355_REQUIRE(total % 32 == 0, "head_logits: voxel count %ld not a multiple of 32", (long)total);
-    int64_t blocks = (total * 8 + 255) / 256;
+    int64_t blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (dtype == MI355_F16)
         hipLaunchKernelGGL(head_logits_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, (const _Float16 *)feat,
@@ -271,12 +259,10 @@ template <typename T>
 __global__ void head_aggregate_kernel(const T *feat, const float *w, const float *b, int C, int ncls,
                                       MirrorList ml, int P0, int P1, int P2, int nonlin, const float *gauss,
                                       float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0) {
-    const int q = threadIdx.x & 7;
     const int64_t PV = (int64_t)P0 * P1 * P2;
     const int64_t ZYXp = (int64_t)Zp * Yp * Xp;
     const float mult = 1.0f / (float)ml.n;
-    for (int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; v < PV;
-         v += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < PV; v += (int64_t)gridDim.x * blockDim.x) {
         const int px = (int)(v % P2);
         const int py = (int)((v / P2) % P1);
         const int pz = (int)(v / ((int64_t)P2 * P1));
@@ -290,10 +276,10 @@ __global__ void head_aggregate_kernel(const T *feat, const float *w, const float
             const int sx = (m & 4) ? P2 - 1 - px : px;
             const int64_t sv = ((int64_t)sz * P1 + sy) * P2 + sx;
             float lg[HEAD_MAX_CLS];
-            head_dot<T>(feat + ((int64_t)mi * PV + sv) * C, w, b, C, ncls, q, lg);
+            head_dot<T>(feat + ((int64_t)mi * PV + sv) * C, w, b, C, ncls, lg);
             if (nonlin == MI355_NONLIN_SIGMOID) {
 #pragma unroll
-                for (int k = 0; k < HEAD_MAX_CLS; ++k) lg[k] = 1.0f / (1.0f + expf(-lg[k]));
+                for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) lg[k] = 1.0f / (1.0f + expf(-lg[k]));
             } else if (nonlin == MI355_NONLIN_SOFTMAX) {
                 float mx = lg[0];
 #pragma unroll
@@ -302,19 +288,17 @@ __global__ void head_aggregate_kernel(const T *feat, const float *w, const float
 #pragma unroll
                 for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) { lg[k] = expf(lg[k] - mx); den += lg[k]; }
 #pragma unroll
-                for (int k = 0; k < HEAD_MAX_CLS; ++k) lg[k] = lg[k] / den;
+                for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) lg[k] = lg[k] / den;
             }
 #pragma unroll
-            for (int k = 0; k < HEAD_MAX_CLS; ++k) res[k] += mult * lg[k];
+            for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) res[k] += mult * lg[k];
         }
         const float g = gauss ? gauss[v] : 1.0f;
         const int64_t gi = ((int64_t)(z0 + pz) * Yp + (y0 + py)) * Xp + (x0 + px);
 #pragma unroll
         for (int k = 0; k < HEAD_MAX_CLS; ++k)
-            if (k == q && k < ncls)
-                agg[k * ZYXp + gi] += res[k] * g;
-        if (cnt && q == 7)
-            cnt[gi] += g;
+            if (k < ncls) agg[k * ZYXp + gi] += res[k] * g;
+        if (cnt) cnt[gi] += g;
     }
 }
 
@@ -322,13 +306,11 @@ int head_aggregate(const HeadWeights &w, const void *feat, int dtype, int first_
                    int n_mirrors, int P0, int P1, int P2, int nonlin, const float *gauss, float *agg,
                    float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, hipStream_t s) {
     MI355_REQUIRE(n_mirrors >= 1 && n_mirrors <= 8, "head_aggregate: %d mirrors", n_mirrors);
-    MI355_REQUIRE(w.ncls <= 7, "head_aggregate: %d classes (max 7)", w.ncls);
     MirrorList ml;
     ml.n = n_mirrors;
     for (int i = 0; i < 8; ++i) ml.m[i] = i < n_mirrors ? mirrors_host[i] : 0;
     const int64_t PV = (int64_t)P0 * P1 * P2;
-    MI355_REQUIRE(PV % 32 == 0, "head_aggregate: patch voxels %ld not a multiple of 32", (long)PV);
-    int64_t blocks = (PV * 8 + 255) / 256;
+    int64_t blocks = (PV + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (dtype == MI355_F16)
         hipLaunchKernelGGL(head_aggregate_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s,
