@@ -613,7 +613,9 @@ static void fill_geometry(ConvArgs &a, int st, int voxels) {
     a.div_IY = make_fastdiv(a.IY);
 }
 
-int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s) {
+int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name) {
+    const char *kn_dummy;
+    if (!kernel_name) kernel_name = &kn_dummy;
     MI355_REQUIRE(w.wp_dev != nullptr, "conv %d->%d has no MFMA weight pack", w.cin, w.cout);
     MI355_REQUIRE(c.C0 + c.C1 == w.cin_pad, "conv input channels %d+%d != %d", c.C0, c.C1, w.cin_pad);
     MI355_REQUIRE(c.C0 % w.cc == 0 && c.C1 % w.cc == 0, "concat split %d/%d not a multiple of %d", c.C0, c.C1, w.cc);
@@ -653,6 +655,7 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s) {
         const int need = (int)((tiles + 7) / 8) * 8;
         if (gx > need) gx = need;
         dim3 grid(gx, gy);
+        *kernel_name = MF == 4 ? "conv3_f32_mfma_pipe_kernel<4, 1>" : (w.nf == 1 ? "conv3_f32_mfma_pipe_kernel<2, 1>" : "conv3_f32_mfma_pipe_kernel<2, 2>");
         if (MF == 4) return launch_pipe<4, 1>(pa, grid, lds_bytes, s);
         if (w.nf == 1) return launch_pipe<2, 1>(pa, grid, lds_bytes, s);
         return launch_pipe<2, 2>(pa, grid, lds_bytes, s);
@@ -666,12 +669,12 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s) {
     const size_t lds_bytes = brick_bytes < 4096 ? 4096 : brick_bytes;  // >= the stats scratch
     MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
     dim3 grid(tiles_per_n * c.N, w.cout / (32 * w.nf));
-    if (st == 1 && w.cc == 16 && w.nf == 1) return launch_conv<1, 16, 2, 1>(a, grid, lds_bytes, s);
-    if (st == 1 && w.cc == 16 && w.nf == 2) return launch_conv<1, 16, 2, 2>(a, grid, lds_bytes, s);
-    if (st == 1 && w.cc == 8 && w.nf == 1) return launch_conv<1, 8, 2, 1>(a, grid, lds_bytes, s);
-    if (st == 1 && w.cc == 8 && w.nf == 2) return launch_conv<1, 8, 2, 2>(a, grid, lds_bytes, s);
-    if (st == 2 && w.cc == 8 && w.nf == 1) return launch_conv<2, 8, 1, 1>(a, grid, lds_bytes, s);
-    if (st == 2 && w.cc == 8 && w.nf == 2) return launch_conv<2, 8, 1, 2>(a, grid, lds_bytes, s);
+    if (st == 1 && w.cc == 16 && w.nf == 1) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 2, 1>"; return launch_conv<1, 16, 2, 1>(a, grid, lds_bytes, s); }
+    if (st == 1 && w.cc == 16 && w.nf == 2) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 2, 2>"; return launch_conv<1, 16, 2, 2>(a, grid, lds_bytes, s); }
+    if (st == 1 && w.cc == 8 && w.nf == 1) { *kernel_name = "conv3_f32_mfma_kernel<1, 8, 2, 1>"; return launch_conv<1, 8, 2, 1>(a, grid, lds_bytes, s); }
+    if (st == 1 && w.cc == 8 && w.nf == 2) { *kernel_name = "conv3_f32_mfma_kernel<1, 8, 2, 2>"; return launch_conv<1, 8, 2, 2>(a, grid, lds_bytes, s); }
+    if (st == 2 && w.cc == 8 && w.nf == 1) { *kernel_name = "conv3_f32_mfma_kernel<2, 8, 1, 1>"; return launch_conv<2, 8, 1, 1>(a, grid, lds_bytes, s); }
+    if (st == 2 && w.cc == 8 && w.nf == 2) { *kernel_name = "conv3_f32_mfma_kernel<2, 8, 1, 2>"; return launch_conv<2, 8, 1, 2>(a, grid, lds_bytes, s); }
     set_error("no conv kernel for stride %d cc %d nf %d", st, w.cc, w.nf);
     return MI355_ERR_UNSUPPORTED;
 }

@@ -35,7 +35,7 @@ struct ConvCall {
     int act = ACT_NONE;
     float slope = 0.01f;
 };
-int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s);
+int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name = nullptr);
 int conv3d_direct_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s);
 
 // fp16 storage / fp32 accumulate variants (conv3d_f16.hip)

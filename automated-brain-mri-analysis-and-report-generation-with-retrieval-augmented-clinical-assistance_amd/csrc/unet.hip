@@ -211,6 +211,7 @@ struct ProfScope {
         idx = net->prof.size();
         net->prof.push_back(r);
     }
+    void rename(const char *name) { if (on && name) net->prof[idx].name = name; }
     ~ProfScope() { if (on) (void)hipEventRecord(net->prof[idx].b, s); }
 };
 
@@ -247,20 +248,20 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
             c.in0 = (const _Float16 *)in0; c.in1 = (const _Float16 *)in1; c.C0 = C0; c.C1 = C1;
             c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi; c.out = (_Float16 *)out; c.slope = net->slope;
             c.act = act; c.stats = stats_arg;
-            const char *kname = "conv3_f16";
-            // resolve the kernel name first (cheap) so the profiler record carries it
-            ProfScope ps(net, s, L.wh.stride == 1 ? (L.wh.nf == 1 ? "conv3_f16_mfma_pipe_kernel<*, 1>" : "conv3_f16_mfma_pipe_kernel<*, 2>")
-                                                   : (L.wh.nf == 1 ? "conv3_f16_mfma_kernel<2, 1, 1>" : "conv3_f16_mfma_kernel<2, 1, 2>"),
-                         flops, bytes);
+            const char *kname = nullptr;
+            ProfScope ps(net, s, "conv3_f16", flops, bytes);
             MI355_TRY(conv3d_mfma_f16(L.wh, c, s, &kname));
+            ps.rename(kname);
         } else {
             ConvCall c;
             c.in0 = (const float *)in0; c.in1 = (const float *)in1; c.C0 = C0; c.C1 = C1;
             c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi; c.out = (float *)out; c.slope = net->slope;
             c.act = act; c.stats = stats_arg;
+            const char *kname = nullptr;
             ProfScope ps(net, s, conv_kernel_name(L.w), flops, bytes);
-            if (L.w.wp_dev) MI355_TRY(conv3d_mfma_f32(L.w, c, s));
+            if (L.w.wp_dev) MI355_TRY(conv3d_mfma_f32(L.w, c, s, &kname));
             else MI355_TRY(conv3d_direct_f32(L.w, c, s));
+            ps.rename(kname);
         }
     }
     const double es = f16 ? 2.0 : 4.0;
