@@ -109,8 +109,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
 template <int STRIDE, int CC, int MF, int NF>
 __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int S = CC + 4;  // padded voxel stride in floats
-    constexpr int Q = CC / 4;  // 16-B pieces per voxel
+    constexpr int Q = CC / 4;  // 16-B channel quads per voxel = LDS planes
     constexpr int G = CC / 8;  // 8-channel groups per chunk
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -131,14 +130,16 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
     const int IX = p.IX, IY = p.IY;
     const int brickvox = IX * IY * p.IZ;
     const int npieces = brickvox * Q;
+    const int plane = brickvox * 4;  // floats per plane; LDS image is planar [quad][brick voxel][4 floats]:
+                                     // x-consecutive lanes read consecutive 16-B slots (conflict-free, no padding)
 
-    // per-lane LDS base (floats) of each M fragment's voxel at tap (0,0,0)
+    // per-lane LDS offset (floats) of each voxel fragment at tap (0,0,0) in plane `half`
     int a_base[MF];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         const int v = (wave * MF + mf) * 32 + l31;
         const int x = v & TXm, y = (v >> p.lx) & TYm, z = v >> (p.lx + p.ly);
-        a_base[mf] = ((z * STRIDE * IY + y * STRIDE) * IX + x * STRIDE) * S + half * 4;
+        a_base[mf] = half * plane + ((z * STRIDE * IY + y * STRIDE) * IX + x * STRIDE) * 4;
     }
 
     f32x16 acc[MF][NF];
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
     const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * G * NF * 256) + lane * 4;
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
-        // ---- stage the CC-channel input halo brick (zero outside the volume)
+        // ---- stage the CC-channel input halo brick (zero outside the volume); Q lanes share one voxel,
+        //      i.e. CC*4 contiguous bytes per voxel (whole 64-B half lines for CC = 16)
         const int cglob = ch * CC;
         const float *src;
         int Csrc, coff;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
                 const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
                 const bool ok = (i < npieces) && ((unsigned)iz < (unsigned)p.Di) &&
                                 ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
-                dst[u] = (i < npieces) ? bv * S + q * 4 : -1;
+                dst[u] = (i < npieces) ? q * plane + bv * 4 : -1;
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (ok)
                     val = *(const f32x4 *)(src + ((size_t)(iz * p.Hi + iy) * p.Wi + ix) * Csrc + q * 4);
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
                 if (ng == G) { ng = 0; ntap = tap + 1; }
                 if (ntap < 27) {
                     const int dz = ntap / 9, rr = ntap - dz * 9, dy = rr / 3, dx = rr - dy * 3;
-                    const int off = ((dz * IY + dy) * IX + dx) * S + ng * 8;
+                    const int off = ((dz * IY + dy) * IX + dx) * 4 + ng * 2 * plane;
 #pragma unroll
                     for (int mf = 0; mf < MF; ++mf)
                         a_nxt[mf] = *(const f32x4 *)(lds + a_base[mf] + off);
@@ -479,13 +481,18 @@ __global__ void conv3_direct_kernel(const float *in0, const float *in1, int C0, 
 }
 
 // ------------------------------------------------------------------ host side
-static int g_conv_impl = -1;  // from env MI355_CONV_IMPL: "0" = one tile per workgroup kernel, default = pipelined
-static bool use_pipe() {
+// Which stride-1 kernel a layer gets (env MI355_CONV_IMPL: "0" = always the one-tile-per-workgroup kernel,
+// "1" = always the pipelined persistent kernel, default "auto").  Measured on MI355X (bench.py, config 2):
+// both reach ~0.8 of the f32 MFMA peak; the simple kernel with 64-B (16-channel) pieces moves ~40 % fewer
+// bytes through the fabric on the Cout = 32 layers, the pipelined one is ~3 % faster on Cout >= 64 and the stem.
+static int g_conv_impl = -1;
+static bool use_pipe(int cin_pad, int cout) {
     if (g_conv_impl < 0) {
         const char *e = getenv("MI355_CONV_IMPL");
-        g_conv_impl = (e && e[0] == '0') ? 0 : 1;
+        g_conv_impl = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
     }
-    return g_conv_impl == 1;
+    if (g_conv_impl != 2) return g_conv_impl == 1;
+    return !(cout % 64 != 0 && cin_pad % 16 == 0);
 }
 
 // Packed layout (floats): [cout_block][chunk][tap][g][nf][lane 0..63][j 0..3] with
@@ -517,7 +524,7 @@ int conv_weights_upload(const float *w_host, const float *bias_host, int cin, in
     const bool mfma_ok = (cout % 32 == 0) && (cin_pad % 8 == 0);
     if (mfma_ok) {
         // stride 2 bricks are ~8x the output tile: keep them to 8 channels per pass
-        cw.pipe = (stride == 1) && use_pipe();
+        cw.pipe = (stride == 1) && use_pipe(cin_pad, cout);
         cw.cc = (!cw.pipe && stride == 1 && cin_pad % 16 == 0) ? 16 : 8;
         cw.nf = (cout % 64 == 0) ? 2 : 1;
         std::vector<float> packed;
@@ -660,15 +667,22 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
         if (w.nf == 1) return launch_pipe<2, 1>(pa, grid, lds_bytes, s);
         return launch_pipe<2, 2>(pa, grid, lds_bytes, s);
     }
-    const int MF = (st == 1) ? 2 : 1;
+    int MF = (st == 1) ? 4 : 1;
     fill_geometry(a, st, 128 * MF);
+    if (st == 1 && ((long)a.tiles_x * a.tiles_y * a.tiles_z * c.N * (w.cout / (32 * w.nf)) < 512 || w.nf == 2 ||
+                    (size_t)a.IX * a.IY * a.IZ * w.cc * 4 > 80 * 1024)) {
+        MF = 2;
+        fill_geometry(a, st, 128 * MF);
+    }
     const int tiles_per_n = a.tiles_x * a.tiles_y * a.tiles_z;
     MI355_REQUIRE((long)tiles_per_n * c.N < (1l << 30), "conv grid too large");
     const int brickvox = a.IX * a.IY * a.IZ;
-    const size_t brick_bytes = (size_t)brickvox * (w.cc + 4) * sizeof(float);
+    const size_t brick_bytes = (size_t)brickvox * w.cc * sizeof(float);
     const size_t lds_bytes = brick_bytes < 4096 ? 4096 : brick_bytes;  // >= the stats scratch
     MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
     dim3 grid(tiles_per_n * c.N, w.cout / (32 * w.nf));
+    if (st == 1 && w.cc == 16 && MF == 4) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 4, 1>"; return launch_conv<1, 16, 4, 1>(a, grid, lds_bytes, s); }
+    if (st == 1 && w.cc == 8 && MF == 4) { *kernel_name = "conv3_f32_mfma_kernel<1, 8, 4, 1>"; return launch_conv<1, 8, 4, 1>(a, grid, lds_bytes, s); }
     if (st == 1 && w.cc == 16 && w.nf == 1) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 2, 1>"; return launch_conv<1, 16, 2, 1>(a, grid, lds_bytes, s); }
     if (st == 1 && w.cc == 16 && w.nf == 2) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 2, 2>"; return launch_conv<1, 16, 2, 2>(a, grid, lds_bytes, s); }
     if (st == 1 && w.cc == 8 && w.nf == 1) { *kernel_name = "conv3_f32_mfma_kernel<1, 8, 2, 1>"; return launch_conv<1, 8, 2, 1>(a, grid, lds_bytes, s); }
