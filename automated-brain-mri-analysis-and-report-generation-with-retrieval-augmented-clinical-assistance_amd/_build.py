@@ -10,7 +10,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
 LIB_PATH = LIB_DIR / "libmi355_nnunet.so"
-SOURCES = ["conv3d.hip", "conv3d_f16.hip", "tconv.hip", "elementwise.hip", "unet.hip"]
+SOURCES = ["conv3d.hip", "conv3d_f16.hip", "tconv.hip", "elementwise.hip", "extras.hip", "unet.hip"]
 
 
 def find_hipcc() -> str:

@@ -1,0 +1,146 @@
+// "Next" rows of SURVEY.md section 8f that are cheap once the label map is on the device:
+//   * label convention remap          convert_labels_to_brats.py:34-55
+//   * confusion counts for Dice/IoU   evaluate_segmentation.py:12-49,129-195
+//   * cosine top-k retrieval          RAG_Assistant/rag_assistant.py:197-211 (DummyVectorStore.retrieve)
+// All HBM-bound streaming kernels.
+#include "kernels.h"
+
+namespace mi355 {
+
+struct ByteMap { unsigned char m[256]; };
+
+__global__ void label_remap_kernel(const uint8_t *in, uint8_t *out, int64_t n, ByteMap map) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = map.m[in[i]];
+}
+
+// counts[p*K + g] += 1 for every voxel with pred label p, truth label g (labels >= K are clamped to K-1)
+__global__ void confusion_kernel(const uint8_t *pred, const uint8_t *gt, int64_t n, int K, unsigned long long *counts) {
+    __shared__ unsigned int local[64];
+    if (threadIdx.x < 64) local[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int p = pred[i], g = gt[i];
+        p = p < K ? p : K - 1;
+        g = g < K ? g : K - 1;
+        atomicAdd(&local[p * K + g], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < K * K && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)local[threadIdx.x]);
+}
+
+// scores[r] = dot(V[r, :], q): one wave per row, 16-B loads, wave reduction
+__global__ void row_dot_kernel(const float *V, const float *q, int N, int D, float *scores) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < N; r += nwaves) {
+        const float *row = V + (size_t)r * D;
+        float acc = 0.f;
+        if ((D & 3) == 0) {
+            for (int c = lane * 4; c < D; c += 256) {
+                const f32x4 a = *(const f32x4 *)(row + c), b = *(const f32x4 *)(q + c);
+                acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+            }
+        } else {
+            for (int c = lane; c < D; c += 64) acc += row[c] * q[c];
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) scores[r] = acc;
+    }
+}
+
+// one pass of selection: best (score, index) not yet taken; ties -> larger index (np.argsort(scores)[::-1])
+__global__ void argmax_pass_kernel(const float *scores, int N, const int *taken, int n_taken, unsigned long long *best) {
+    unsigned long long loc = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        bool skip = false;
+        for (int t = 0; t < n_taken; ++t) skip |= (taken[t] == i);
+        if (skip) continue;
+        // order-preserving map of the float bits, index in the low word
+        unsigned int u = __float_as_uint(scores[i]);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        const unsigned long long key = ((unsigned long long)u << 32) | (unsigned int)i;
+        loc = key > loc ? key : loc;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(loc, off);
+        loc = o > loc ? o : loc;
+    }
+    if ((threadIdx.x & 63) == 0 && loc) atomicMax(best, loc);
+}
+
+__global__ void take_best_kernel(const unsigned long long *best, const float *scores, int *taken, int slot, int *out_idx,
+                                 float *out_score) {
+    const int idx = (int)(*best & 0xffffffffu);
+    taken[slot] = idx;
+    out_idx[slot] = idx;
+    out_score[slot] = scores[idx];
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" int mi355_label_remap(const uint8_t *in_dev, uint8_t *out_dev, int64_t n, const uint8_t *map256_host, void *stream) {
+    MI355_REQUIRE(in_dev && out_dev && map256_host && n >= 0, "bad argument");
+    ByteMap bm;
+    for (int i = 0; i < 256; ++i) bm.m[i] = map256_host[i];
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(label_remap_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in_dev, out_dev, n, bm);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+extern "C" int mi355_label_confusion(const uint8_t *pred_dev, const uint8_t *gt_dev, int64_t n, int K, uint64_t *counts_host,
+                                     void *stream) {
+    MI355_REQUIRE(pred_dev && gt_dev && counts_host && K >= 2 && K <= 8, "bad argument (2 <= K <= 8)");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *c = nullptr;
+    MI355_HIP(hipMalloc(&c, 64 * sizeof(unsigned long long)));
+    MI355_HIP(hipMemsetAsync(c, 0, 64 * sizeof(unsigned long long), s));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred_dev, gt_dev, n, K, c);
+    unsigned long long h[64];
+    hipError_t e = hipMemcpyAsync(h, c, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(c);
+    MI355_HIP(e);
+    for (int i = 0; i < K * K; ++i) counts_host[i] = h[i];
+    return MI355_OK;
+}
+
+extern "C" int mi355_cosine_topk(const float *vectors_dev, const float *query_dev, int N, int D, int k, int32_t *idx_host,
+                                 float *scores_host, void *stream) {
+    MI355_REQUIRE(vectors_dev && query_dev && idx_host && scores_host && N >= 1 && D >= 1 && k >= 1 && k <= 64, "bad argument");
+    if (k > N) k = N;
+    hipStream_t s = (hipStream_t)stream;
+    float *scores = nullptr, *out_s = nullptr;
+    int *taken = nullptr, *out_i = nullptr;
+    unsigned long long *best = nullptr;
+    MI355_HIP(hipMalloc(&scores, (size_t)N * sizeof(float)));
+    MI355_HIP(hipMalloc(&out_s, 64 * sizeof(float)));
+    MI355_HIP(hipMalloc(&taken, 64 * sizeof(int)));
+    MI355_HIP(hipMalloc(&out_i, 64 * sizeof(int)));
+    MI355_HIP(hipMalloc(&best, sizeof(unsigned long long)));
+    int blocks = (int)(((int64_t)N * 64 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(row_dot_kernel, dim3(blocks), dim3(256), 0, s, vectors_dev, query_dev, N, D, scores);
+    int b2 = (N + 255) / 256;
+    if (b2 > 1024) b2 = 1024;
+    for (int t = 0; t < k; ++t) {
+        (void)hipMemsetAsync(best, 0, sizeof(unsigned long long), s);
+        hipLaunchKernelGGL(argmax_pass_kernel, dim3(b2), dim3(256), 0, s, scores, N, taken, t, best);
+        hipLaunchKernelGGL(take_best_kernel, dim3(1), dim3(1), 0, s, best, scores, taken, t, out_i, out_s);
+    }
+    hipError_t e = hipMemcpyAsync(idx_host, out_i, k * sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(scores_host, out_s, k * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(scores); (void)hipFree(out_s); (void)hipFree(taken); (void)hipFree(out_i); (void)hipFree(best);
+    MI355_HIP(e);
+    return k;
+}

@@ -143,6 +143,18 @@ int mi355_prob_mean(const float *a_dev, const float *b_dev, float *out_dev, int6
 /* Per channel: x[m] = (x[m]-mean(x[m]))/(std(x[m])+1e-8) ; x[~m] = 0  (m = mask != 0, ddof 0). */
 int mi355_zscore_masked(float *vol_dev, const uint8_t *mask_dev, int C, int64_t voxels, void *stream);
 
+/* ---- rows SURVEY.md 8f marks "next" (consumers of the label map / config 5's retrieval step) ---- */
+/* out[i] = map[in[i]] (convert_labels_to_brats.py:34-55: nnU-Net {1,2,3} -> BraTS2025 {2,1,3} / BraTS2021 {2,1,4}). */
+int mi355_label_remap(const uint8_t *in_dev, uint8_t *out_dev, int64_t n, const uint8_t *map256_host, void *stream);
+/* counts_host[p*K+g] = #voxels with prediction p and ground truth g: everything evaluate_segmentation.py:12-49,
+ * 129-195 derives (Dice, IoU, sensitivity, specificity per label and for WT/TC/ET) follows from these integers. */
+int mi355_label_confusion(const uint8_t *pred_dev, const uint8_t *gt_dev, int64_t n, int K, uint64_t *counts_host,
+                          void *stream);
+/* scores = V @ q over L2-normalised rows, top-k by score (RAG_Assistant/rag_assistant.py:197-211).
+ * vectors_dev [N][D] fp32, query_dev [D]; returns the number of results written (<= k) or < 0. */
+int mi355_cosine_topk(const float *vectors_dev, const float *query_dev, int N, int D, int k, int32_t *idx_host,
+                      float *scores_host, void *stream);
+
 /* Per-kernel timing with HIP events on the stream the kernels are launched on (bench.py's
  * roofline). flops / bytes are the ALGORITHMIC work of the recorded launches. */
 typedef struct {

@@ -1,0 +1,75 @@
+"""-m gpu: SURVEY 8f rows (label conversion, evaluator, cosine top-k) against the reference's own
+numpy expressions (oracle/extras_ref.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import extras_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _labels(rs, shape, p=(0.7, 0.1, 0.1, 0.1)):
+    return rs.choice(len(p), size=shape, p=p).astype(np.uint8)
+
+
+@pytest.mark.parametrize("fmt", ["brats2025", "brats2021"])
+def test_convert_labels(amd, gpu, fmt):
+    seg = _labels(np.random.RandomState(1), (24, 30, 28))
+    got = amd.evaluate.convert_labels(torch.from_numpy(seg).to(gpu), fmt).cpu().numpy()
+    assert np.array_equal(got, extras_ref.convert_labels(seg, fmt))
+
+
+def test_evaluator_matches_reference_formulas(amd, gpu):
+    rs = np.random.RandomState(2)
+    gt = _labels(rs, (155, 240, 240), (0.97, 0.01, 0.012, 0.008))
+    pred = gt.copy()
+    flip = rs.uniform(size=gt.shape) < 0.02
+    pred[flip] = _labels(rs, int(flip.sum()), (0.4, 0.2, 0.2, 0.2))
+    res = amd.evaluate.evaluate(torch.from_numpy(pred).to(gpu), torch.from_numpy(gt).to(gpu))
+    for lab in (1, 2, 3):
+        want = extras_ref.calculate_metrics(pred, gt, lab)
+        for k in ("dice", "iou", "sensitivity", "specificity", "tp", "fp", "fn", "tn"):
+            assert res[lab][k] == pytest.approx(want[k], rel=1e-12, abs=1e-12), (lab, k)
+    comp = extras_ref.compound(pred, gt)
+    for name in ("WT", "TC", "ET"):
+        for k in ("dice", "iou", "sensitivity"):
+            assert res[name][k] == pytest.approx(comp[name][k], rel=1e-12)
+    assert res["mean_dice"] == pytest.approx(comp["mean_dice"], rel=1e-12)
+    same = amd.evaluate.evaluate(torch.from_numpy(gt).to(gpu), torch.from_numpy(gt).to(gpu))
+    assert same["mean_dice"] == pytest.approx(1.0)
+    with pytest.raises(ValueError):
+        amd.evaluate.confusion(torch.from_numpy(gt).to(gpu), torch.from_numpy(gt[:10]).to(gpu))
+
+
+DOCS = [{"term": "glioma", "text": "A glioma is a tumour that starts in the glial cells of the brain or spine."},
+        {"term": "edema", "text": "Peritumoral edema is swelling around a tumour caused by fluid accumulation."},
+        {"term": "necrosis", "text": "Necrotic core refers to dead tissue in the centre of the tumour."},
+        {"term": "enhancing", "text": "Enhancing tumour is the region that takes up contrast on T1ce MRI."},
+        {"term": "flair", "text": "FLAIR is an MRI sequence that suppresses fluid signal to show edema."},
+        {"term": "segmentation", "text": "Segmentation assigns every voxel of the MRI volume to a tissue label."},
+        {"term": "dice", "text": "The Dice score measures the overlap between prediction and ground truth."}]
+
+
+def test_dummy_vector_store_retrieve(amd, gpu):
+    ref = extras_ref.DummyVectorStoreRef(DOCS)
+    store = amd.retrieval.DummyVectorStore(DOCS)
+    assert store.vocab == ref.vocab
+    for q in ("what is edema around the tumour", "explain the dice overlap score", "which MRI sequence shows fluid", "zzz"):
+        want = ref.retrieve(q, 2)
+        got = store.retrieve(q, 2)
+        assert [d["term"] for d, _ in got] == [d["term"] for d, _ in want], q
+        assert np.allclose([s for _, s in got], [s for _, s in want], atol=1e-6)
+
+
+def test_cosine_topk_large(amd, gpu):
+    rs = np.random.RandomState(3)
+    v = rs.standard_normal((200000, 384)).astype(np.float32)
+    idx = amd.retrieval.VectorIndex(v)
+    q = rs.standard_normal(384)
+    q /= np.linalg.norm(q)
+    got = idx.topk(q, 5)
+    scores = idx.host @ q
+    want = np.argsort(scores)[::-1][:5]
+    assert [i for i, _ in got] == list(want)
+    assert np.allclose([s for _, s in got], scores[want], atol=1e-5)
