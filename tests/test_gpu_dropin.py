@@ -71,3 +71,45 @@ def test_dropin_missing_models_exit_code(amd, gpu, tmp_path):
                           "--input", str(tmp_path / "in"), "--output", str(tmp_path / "out"),
                           "--results_folder", str(tmp_path / "none")], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert res.returncode == 1 and "[ERROR] Model not found" in res.stdout
+
+
+def test_nnunet_predict_cli_save_npz_and_probability_ensemble(amd, gpu, tmp_path):
+    """nnUNet_predict-style surface (archived/kaist_original_inference.py:30-32): per-model prediction with
+    --save_npz, then nnUNet_ensemble = mean of the two probability maps, thresholded once."""
+    patch = (32, 32, 32)
+    results = tmp_path / "nnUNet_results"
+    base = results / "3d_fullres" / "Task500_BraTS2021"
+    plans = amd.checkpoint.default_brats_plans(patch)
+    tr1, tr2 = amd.driver.MODEL1.split("__")[0], amd.driver.MODEL2.split("__")[0]
+    sds1 = [amd.synthetic.make_model("A", seed=60, num_pool=2, max_feat=128)[0]]
+    sds2 = [amd.synthetic.make_model("B", seed=61, num_pool=2, max_feat=128)[0]]
+    amd.checkpoint.save_model_folder(base / amd.driver.MODEL1, tr1, sds1, plans)
+    amd.checkpoint.save_model_folder(base / amd.driver.MODEL2, tr2, sds2, plans)
+    raw_dir = tmp_path / "raw"
+    raw_dir.mkdir()
+    raw = _write_case(amd, raw_dir, "case", (36, 44, 40), seed=78)
+    in_dir = tmp_path / "imagesTs"
+    amd.driver.prepare_input(raw_dir, in_dir)
+    env = dict(os.environ, RESULTS_FOLDER=str(results))
+    outs = []
+    for k, tr in enumerate((tr1, tr2)):
+        out = tmp_path / f"out{k}"
+        res = subprocess.run([sys.executable, "-m", "brats_amd.nnunet_predict", "-i", str(in_dir), "-o", str(out), "-t", "500",
+                              "-m", "3d_fullres", "-tr", tr, "-f", "0", "--save_npz"], env=env, cwd=ROOT,
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+        assert (out / "case.nii.gz").exists() and (out / "case.npz").exists()
+        outs.append(out)
+    ens = tmp_path / "ens"
+    res = subprocess.run([sys.executable, "-m", "brats_amd.nnunet_predict", "--ensemble", str(outs[0]), str(outs[1]), "-o", str(ens)],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    got = amd.nifti.load(ens / "case.nii.gz").as_zyx()
+    _, p1, props = driver_ref.predict_case(raw, sds1, unet_ref.default_cfg("batch"), patch)
+    _, p2, _ = driver_ref.predict_case(raw, sds2, unet_ref.default_cfg("group", 16), patch)
+    want = tiler_ref.paste_into_original(tiler_ref.regions_to_labels((p1 + p2) / 2.0), props["crop_bbox"],
+                                         props["original_size_of_raw_data"])
+    assert tiler_ref.brats_region_dice(got, want)["mean"] >= 0.999
+    missing = subprocess.run([sys.executable, "-m", "brats_amd.nnunet_predict", "-i", str(in_dir), "-o", str(tmp_path / "x"),
+                              "-tr", "nnUNetTrainerDoesNotExist"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert missing.returncode == 1 and "[ERROR] Model not found" in missing.stdout
