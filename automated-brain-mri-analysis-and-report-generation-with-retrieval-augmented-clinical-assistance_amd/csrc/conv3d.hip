@@ -481,18 +481,19 @@ __global__ void conv3_direct_kernel(const float *in0, const float *in1, int C0, 
 }
 
 // ------------------------------------------------------------------ host side
-// Which stride-1 kernel a layer gets (env MI355_CONV_IMPL: "0" = always the one-tile-per-workgroup kernel,
+// Which stride-1 kernel a launch gets (env MI355_CONV_IMPL: "0" = always the one-tile-per-workgroup kernel,
 // "1" = always the pipelined persistent kernel, default "auto").  Measured on MI355X (bench.py, config 2):
-// both reach ~0.8 of the f32 MFMA peak; the simple kernel with 64-B (16-channel) pieces moves ~40 % fewer
-// bytes through the fabric on the Cout = 32 layers, the pipelined one is ~3 % faster on Cout >= 64 and the stem.
-static int g_conv_impl = -1;
-static bool use_pipe(int cin_pad, int cout) {
-    if (g_conv_impl < 0) {
+// the simple kernel with 512-voxel tiles (MF = 4) and 16-channel chunks reaches 0.81 (Cout 32) / 0.87 (Cout >= 64)
+// of the f32 MFMA peak and moves ~40 % fewer bytes through the fabric, but needs >= 512 workgroups of that size;
+// launches with fewer tiles (deep levels, small batches) and the 8-channel stem go to the pipelined kernel, which
+// keeps 2 workgroups per CU busy with 256-voxel tiles.  Auto mode therefore keeps two weight packs per layer.
+static int conv_impl() {
+    static int v = -1;
+    if (v < 0) {
         const char *e = getenv("MI355_CONV_IMPL");
-        g_conv_impl = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
+        v = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
     }
-    if (g_conv_impl != 2) return g_conv_impl == 1;
-    return !(cout % 64 != 0 && cin_pad % 16 == 0);
+    return v;
 }
 
 // Packed layout (floats): [cout_block][chunk][tap][g][nf][lane 0..63][j 0..3] with
@@ -524,7 +525,7 @@ int conv_weights_upload(const float *w_host, const float *bias_host, int cin, in
     const bool mfma_ok = (cout % 32 == 0) && (cin_pad % 8 == 0);
     if (mfma_ok) {
         // stride 2 bricks are ~8x the output tile: keep them to 8 channels per pass
-        cw.pipe = (stride == 1) && use_pipe(cin_pad, cout);
+        cw.pipe = (stride == 1) && conv_impl() != 0;
         cw.cc = (!cw.pipe && stride == 1 && cin_pad % 16 == 0) ? 16 : 8;
         cw.nf = (cout % 64 == 0) ? 2 : 1;
         std::vector<float> packed;
@@ -532,6 +533,11 @@ int conv_weights_upload(const float *w_host, const float *bias_host, int cin, in
         cw.wp_bytes = packed.size() * sizeof(float);
         MI355_HIP(hipMalloc(&cw.wp_dev, cw.wp_bytes));
         MI355_HIP(hipMemcpy(cw.wp_dev, packed.data(), cw.wp_bytes, hipMemcpyHostToDevice));
+        if (stride == 1 && conv_impl() == 2 && cin_pad % 16 == 0) {
+            pack_conv_weights_f32(w_host, cin, cin_pad, cout, 16, cw.nf, packed);
+            MI355_HIP(hipMalloc(&cw.wp16_dev, packed.size() * sizeof(float)));
+            MI355_HIP(hipMemcpy(cw.wp16_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     if (keep_plain || !mfma_ok) {
         // the direct kernel indexes channels of the (possibly zero-padded) input tensors
@@ -554,6 +560,7 @@ int conv_weights_upload(const float *w_host, const float *bias_host, int cin, in
 
 void conv_weights_free(ConvWeights *w) {
     if (w->wp_dev) (void)hipFree(w->wp_dev);
+    if (w->wp16_dev) (void)hipFree(w->wp16_dev);
     if (w->bias_dev) (void)hipFree(w->bias_dev);
     if (w->w_plain_dev) (void)hipFree(w->w_plain_dev);
     *w = ConvWeights();
@@ -636,6 +643,21 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
     a.Cout = w.cout;
     a.nchunks = w.cin_pad / w.cc;
     a.act = c.act; a.slope = c.slope;
+    if (w.wp16_dev) {
+        // auto mode: 512-voxel tiles + 16-channel chunks when that fills the chip
+        ConvArgs b = a;
+        fill_geometry(b, 1, 512);
+        const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
+        const size_t brick_bytes = (size_t)b.IX * b.IY * b.IZ * 16 * sizeof(float);
+        if (tiles * (w.cout / (32 * w.nf)) >= 512 && brick_bytes <= 80 * 1024 && tiles < (1l << 30)) {
+            b.wp = w.wp16_dev;
+            b.nchunks = w.cin_pad / 16;
+            dim3 grid((unsigned)tiles, w.cout / (32 * w.nf));
+            if (w.nf == 2) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 4, 2>"; return launch_conv<1, 16, 4, 2>(b, grid, brick_bytes, s); }
+            *kernel_name = "conv3_f32_mfma_kernel<1, 16, 4, 1>";
+            return launch_conv<1, 16, 4, 1>(b, grid, brick_bytes, s);
+        }
+    }
     if (w.pipe) {
         const int gy = w.cout / (32 * w.nf);
         // 4 voxel fragments per wave (512-voxel tiles) when that still gives every CU two workgroups
@@ -669,8 +691,8 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
     }
     int MF = (st == 1) ? 4 : 1;
     fill_geometry(a, st, 128 * MF);
-    if (st == 1 && ((long)a.tiles_x * a.tiles_y * a.tiles_z * c.N * (w.cout / (32 * w.nf)) < 512 || w.nf == 2 ||
-                    (size_t)a.IX * a.IY * a.IZ * w.cc * 4 > 80 * 1024)) {
+    if (st == 1 && ((long)a.tiles_x * a.tiles_y * a.tiles_z * c.N * (w.cout / (32 * w.nf)) < 512 ||
+                    (size_t)a.IX * a.IY * a.IZ * w.cc * 4 > 80 * 1024 || (w.cc == 8 && w.nf == 2))) {
         MF = 2;
         fill_geometry(a, st, 128 * MF);
     }
@@ -681,8 +703,9 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
     const size_t lds_bytes = brick_bytes < 4096 ? 4096 : brick_bytes;  // >= the stats scratch
     MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
     dim3 grid(tiles_per_n * c.N, w.cout / (32 * w.nf));
+    if (st == 1 && w.cc == 16 && MF == 4 && w.nf == 2) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 4, 2>"; return launch_conv<1, 16, 4, 2>(a, grid, lds_bytes, s); }
     if (st == 1 && w.cc == 16 && MF == 4) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 4, 1>"; return launch_conv<1, 16, 4, 1>(a, grid, lds_bytes, s); }
-    if (st == 1 && w.cc == 8 && MF == 4) { *kernel_name = "conv3_f32_mfma_kernel<1, 8, 4, 1>"; return launch_conv<1, 8, 4, 1>(a, grid, lds_bytes, s); }
+    if (st == 1 && w.cc == 8 && MF == 4 && w.nf == 1) { *kernel_name = "conv3_f32_mfma_kernel<1, 8, 4, 1>"; return launch_conv<1, 8, 4, 1>(a, grid, lds_bytes, s); }
     if (st == 1 && w.cc == 16 && w.nf == 1) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 2, 1>"; return launch_conv<1, 16, 2, 1>(a, grid, lds_bytes, s); }
     if (st == 1 && w.cc == 16 && w.nf == 2) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 2, 2>"; return launch_conv<1, 16, 2, 2>(a, grid, lds_bytes, s); }
     if (st == 1 && w.cc == 8 && w.nf == 1) { *kernel_name = "conv3_f32_mfma_kernel<1, 8, 2, 1>"; return launch_conv<1, 8, 2, 1>(a, grid, lds_bytes, s); }

@@ -15,7 +15,8 @@ struct ConvWeights {
     int cc = 0;               // channel chunk staged in LDS per pass
     int nf = 1;               // 32-wide cout fragments per workgroup
     bool pipe = false;        // pipelined (persistent, double-buffered) kernel; implies cc == 8
-    float *wp_dev = nullptr;  // packed weights (device)
+    float *wp_dev = nullptr;  // packed weights (device), chunk size cc
+    float *wp16_dev = nullptr;  // second pack with 16-channel chunks for the 512-voxel-tile simple kernel (auto mode)
     float *bias_dev = nullptr;
     float *w_plain_dev = nullptr;  // [cout][cin][27] PyTorch order (direct kernel / tests)
     size_t wp_bytes = 0;
