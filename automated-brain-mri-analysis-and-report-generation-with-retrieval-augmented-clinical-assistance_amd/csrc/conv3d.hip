@@ -263,6 +263,7 @@ struct PipeArgs {
     int total_tiles;   // N * tiles per sample
     int plane;         // floats per LDS plane (= brickvox * 4)
     int buf_floats;    // floats per LDS buffer (= 2 * plane)
+    int w_split;       // the weight pack interleaves NF*w_split cout fragments per tap; this launch takes NF of them per block
 };
 
 template <int MF, int NF>
@@ -345,7 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_pipe_kernel(PipeArgs pa
             for (int r = 0; r < 16; ++r)
                 acc[mf][nf][r] = 0.f;
 
-    const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 256) + lane * 4;
+    const int NFP = NF * pa.w_split;  // fragments per tap in the pack
+    const float *wblk = p.wp + (size_t)((int)blockIdx.y / pa.w_split) * p.nchunks * (27 * NFP * 256) +
+                        ((int)blockIdx.y % pa.w_split) * (NF * 256) + lane * 4;
     const int co_blk = (int)blockIdx.y * NF * 32;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_pipe_kernel(PipeArgs pa
 #pragma unroll
     for (int k = 0; k < BD; ++k)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) bq[k][nf] = *(const f32x4 *)(wblk + (size_t)k * (NF * 256) + nf * 256);
+        for (int nf = 0; nf < NF; ++nf) bq[k][nf] = *(const f32x4 *)(wblk + (size_t)k * (NFP * 256) + nf * 256);
     __syncthreads();
 
     int ch = 0, buf = 0;
@@ -374,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_pipe_kernel(PipeArgs pa
         const int nch_eff = have_next ? nch : ch;  // last chunk of this workgroup: harmless re-read
         const float *bufc = lds + buf * pa.buf_floats;
         float *bufn = lds + (buf ^ 1) * pa.buf_floats;
-        const float *wch = wblk + (size_t)ch * (27 * NF * 256);
-        const float *wnx = wblk + (size_t)nch_eff * (27 * NF * 256);
+        const float *wch = wblk + (size_t)ch * (27 * NFP * 256);
+        const float *wnx = wblk + (size_t)nch_eff * (27 * NFP * 256);
 
         f32x4 a[2][MF];
 #pragma unroll
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_pipe_kernel(PipeArgs pa
                         acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[tap % BD][nf][j], a[tap & 1][mf][j], acc[mf][nf], 0, 0, 0);
             {   // refill this ring slot with the fragment BD steps ahead (possibly of the next chunk)
                 const int k = tap + BD;
-                const float *wsrc = (k < 27) ? wch + (size_t)k * (NF * 256) : wnx + (size_t)(k - 27) * (NF * 256);
+                const float *wsrc = (k < 27) ? wch + (size_t)k * (NFP * 256) : wnx + (size_t)(k - 27) * (NFP * 256);
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) bq[tap % BD][nf] = *(const f32x4 *)(wsrc + nf * 256);
             }
@@ -659,16 +662,19 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
         }
     }
     if (w.pipe) {
-        const int gy = w.cout / (32 * w.nf);
-        // 4 voxel fragments per wave (512-voxel tiles) when that still gives every CU two workgroups
-        int MF = 4;
-        fill_geometry(a, 1, 128 * MF);
-        long tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * c.N;
-        if (tiles * gy < 512 || a.IX * a.IY * a.IZ > 11 * 128 || w.nf == 2) {  // (4,2) needs > 256 VGPRs
-            MF = 2;
-            fill_geometry(a, 1, 128 * MF);
-            tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * c.N;
+        // tile size / couts per workgroup: as large as still gives the chip >= ~2 workgroups per CU; launches with
+        // few voxels and many channels (deep levels) fall back to 256- then 128-voxel tiles and 32-cout blocks
+        int MF = 4, NF = 1;
+        long tiles = 0;
+        auto geom = [&](int mf) { fill_geometry(a, 1, 128 * mf); tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * c.N; };
+        geom(4);
+        if (w.nf == 2 || tiles * (w.cout / 32) < 512 || a.IX * a.IY * a.IZ > 11 * 128) {
+            MF = 2; NF = w.nf;
+            geom(2);
+            if (tiles * (w.cout / (32 * NF)) < 384) NF = 1;
+            if (tiles * (w.cout / (32 * NF)) < 384) { MF = 1; geom(1); }
         }
+        const int gy = w.cout / (32 * NF);
         MI355_REQUIRE(tiles < (1l << 30), "conv grid too large");
         const int brickvox = a.IX * a.IY * a.IZ;
         MI355_REQUIRE(brickvox <= (MF == 4 ? 11 : 8) * 128, "conv brick of %d voxels exceeds the staging slots", brickvox);
@@ -677,17 +683,19 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
         pa.total_tiles = (int)tiles;
         pa.plane = brickvox * 4;
         pa.buf_floats = 2 * pa.plane;
-        const size_t lds_bytes = (size_t)(2 * pa.buf_floats + 4 * w.nf * 32 * 2) * sizeof(float);
+        pa.w_split = w.nf / NF;
+        const size_t lds_bytes = (size_t)(2 * pa.buf_floats + 4 * NF * 32 * 2) * sizeof(float);
         MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
         int gx = 512 / gy;                      // ~2 resident workgroups per CU in total
         gx = gx < 8 ? 8 : (gx / 8) * 8;         // multiple of 8: blockIdx.x & 7 labels the XCD group
         const int need = (int)((tiles + 7) / 8) * 8;
         if (gx > need) gx = need;
         dim3 grid(gx, gy);
-        *kernel_name = MF == 4 ? "conv3_f32_mfma_pipe_kernel<4, 1>" : (w.nf == 1 ? "conv3_f32_mfma_pipe_kernel<2, 1>" : "conv3_f32_mfma_pipe_kernel<2, 2>");
-        if (MF == 4) return launch_pipe<4, 1>(pa, grid, lds_bytes, s);
-        if (w.nf == 1) return launch_pipe<2, 1>(pa, grid, lds_bytes, s);
-        return launch_pipe<2, 2>(pa, grid, lds_bytes, s);
+        if (MF == 4) { *kernel_name = "conv3_f32_mfma_pipe_kernel<4, 1>"; return launch_pipe<4, 1>(pa, grid, lds_bytes, s); }
+        if (MF == 2 && NF == 2) { *kernel_name = "conv3_f32_mfma_pipe_kernel<2, 2>"; return launch_pipe<2, 2>(pa, grid, lds_bytes, s); }
+        if (MF == 2) { *kernel_name = "conv3_f32_mfma_pipe_kernel<2, 1>"; return launch_pipe<2, 1>(pa, grid, lds_bytes, s); }
+        *kernel_name = "conv3_f32_mfma_pipe_kernel<1, 1>";
+        return launch_pipe<1, 1>(pa, grid, lds_bytes, s);
     }
     int MF = (st == 1) ? 4 : 1;
     fill_geometry(a, st, 128 * MF);
