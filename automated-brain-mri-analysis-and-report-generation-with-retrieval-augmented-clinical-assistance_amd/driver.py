@@ -73,7 +73,9 @@ class LoadedModel:
 
 def read_case(list_of_files: Sequence[str]):
     """The four modality files -> float32 [4, Z, Y, X] (SimpleITK axis order) + the first image (geometry)."""
-    imgs = [nifti.load(f) for f in list_of_files]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(list_of_files)) as pool:  # gunzip releases the GIL: 4 files in parallel
+        imgs = list(pool.map(nifti.load, list_of_files))
     shapes = {im.data.shape for im in imgs}
     if len(shapes) != 1:
         raise ValueError(f"modalities have different shapes: {shapes}")

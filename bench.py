@@ -55,7 +55,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run (any N)
+    if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
     # ---- workload
@@ -93,8 +94,8 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
@@ -107,7 +108,7 @@ def main():
         seg = step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -121,7 +122,7 @@ def main():
     label_hist = torch.bincount(seg.flatten().to(torch.int64), minlength=4).tolist()
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -185,7 +186,7 @@ def main():
         "speedup_vs_nominal_5min": round(300.0 / (elapsed / args.steps), 1),
     }
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
