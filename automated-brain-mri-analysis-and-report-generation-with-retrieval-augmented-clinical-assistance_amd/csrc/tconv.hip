@@ -79,6 +79,78 @@ __global__ __launch_bounds__(256) void tconv2_f32_mfma_kernel(const float *__res
     }
 }
 
+// Version 2: one workgroup = 128 input voxels (4 voxel fragments) x 32 couts x ALL 8 output parities; wave w owns
+// parities {2w, 2w+1}.  Per 8-channel group a wave reads 4 voxel fragments (B operand, straight from global, L1-shared
+// by the four waves) and 2 weight fragments (A operand) for 32 MFMAs; D = W^T x X so a lane holds one voxel and 16
+// couts -> 16-B stores.  The input is read Cout/32 times in total instead of 8*Cout/32.
+__global__ __launch_bounds__(256) void tconv2_f32_mfma_v2_kernel(const float *__restrict__ in,
+                                                                const float *__restrict__ wp, float *out, int M,
+                                                                int Cin, int Cout, int D, int H, int W, FastDiv divW,
+                                                                FastDiv divH, FastDiv divD) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nblk = Cout >> 5;
+    const int nb = (int)blockIdx.y;
+    const int G = Cin >> 3;
+    const int m0 = (int)blockIdx.x * 128;
+    const float *xrow[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        int v = m0 + mf * 32 + l31;
+        if (v >= M) v = M - 1;
+        xrow[mf] = in + (size_t)v * Cin + half * 4;
+    }
+    const float *wrow[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) wrow[pp] = wp + ((size_t)((wave * 2 + pp) * nblk + nb) * G) * 256 + lane * 4;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pp][mf][r] = 0.f;
+#pragma unroll 2
+    for (int g = 0; g < G; ++g) {
+        f32x4 x[4], wv[2];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) x[mf] = *(const f32x4 *)(xrow[mf] + g * 8);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) wv[pp] = *(const f32x4 *)(wrow[pp] + (size_t)g * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    acc[pp][mf] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[pp][j], x[mf][j], acc[pp][mf], 0, 0, 0);
+    }
+    const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int v = m0 + mf * 32 + l31;
+        if (v < M) {
+            const uint32_t q1 = fdiv((uint32_t)v, divW);
+            const int x = v - (int)q1 * W;
+            const uint32_t q2 = fdiv(q1, divH);
+            const int y = (int)q1 - (int)q2 * H;
+            const uint32_t n = fdiv(q2, divD);
+            const int z = (int)q2 - (int)n * D;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int pos = wave * 2 + pp;
+                const int pa = pos >> 2, pb = (pos >> 1) & 1, pc = pos & 1;
+                float *o = out + ((((size_t)n * Do + 2 * z + pa) * Ho + 2 * y + pb) * Wo + 2 * x + pc) * Cout + nb * 32 + 4 * half;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 val = {acc[pp][mf][4 * g4], acc[pp][mf][4 * g4 + 1], acc[pp][mf][4 * g4 + 2], acc[pp][mf][4 * g4 + 3]};
+                    *(f32x4 *)(o + 8 * g4) = val;
+                }
+            }
+        }
+    }
+}
+
 // pack: [pos = a*4+b*2+c][cout block][g][lane][j]; cout = nb*32 + (lane&31), cin = g*8 + (lane>>5)*4 + j
 int tconv_weights_upload(const float *w_host, int cin, int cout, TConvWeights *out) {
     MI355_REQUIRE(cin % 8 == 0 && cout % 32 == 0, "tconv %d->%d: need cin %% 8 == 0 and cout %% 32 == 0", cin, cout);
@@ -111,6 +183,15 @@ int tconv2_mfma_f32(const TConvWeights &w, const float *in, int N, int D, int H,
                     hipStream_t s) {
     const long M = (long)N * D * H * W;
     MI355_REQUIRE(M > 0 && M < (1l << 30), "tconv: %ld voxels out of range", M);
+    static int v1 = -1;
+    if (v1 < 0) { const char *e = getenv("MI355_TCONV_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
+    if (!v1) {
+        dim3 grid((unsigned)((M + 127) / 128), w.cout / 32);
+        hipLaunchKernelGGL(tconv2_f32_mfma_v2_kernel, grid, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cin, w.cout, D, H, W,
+                           make_fastdiv(W), make_fastdiv(H), make_fastdiv(D));
+        MI355_HIP(hipGetLastError());
+        return MI355_OK;
+    }
     constexpr int MF = 2;
     dim3 grid((unsigned)((M + 4 * MF * 32 - 1) / (4 * MF * 32)), 8 * (w.cout / 32));
     hipLaunchKernelGGL(tconv2_f32_mfma_kernel<MF>, grid, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cin,
@@ -179,6 +260,74 @@ __global__ __launch_bounds__(256) void tconv2_f16_mfma_kernel(const _Float16 *__
     }
 }
 
+// Version 2 (same decomposition as tconv2_f32_mfma_v2_kernel): 128 voxels x 32 couts x 8 parities per workgroup.
+__global__ __launch_bounds__(256) void tconv2_f16_mfma_v2_kernel(const _Float16 *__restrict__ in,
+                                                                const _Float16 *__restrict__ wp, _Float16 *out, int M,
+                                                                int Cin, int Cout, int D, int H, int W, FastDiv divW,
+                                                                FastDiv divH, FastDiv divD) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nblk = Cout >> 5;
+    const int nb = (int)blockIdx.y;
+    const int G = Cin >> 4;
+    const int m0 = (int)blockIdx.x * 128;
+    const _Float16 *xrow[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        int v = m0 + mf * 32 + l31;
+        if (v >= M) v = M - 1;
+        xrow[mf] = in + (size_t)v * Cin + half * 8;
+    }
+    const _Float16 *wrow[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) wrow[pp] = wp + ((size_t)((wave * 2 + pp) * nblk + nb) * G) * 512 + lane * 8;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pp][mf][r] = 0.f;
+#pragma unroll 2
+    for (int g = 0; g < G; ++g) {
+        f16x8 x[4], wv[2];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) x[mf] = *(const f16x8 *)(xrow[mf] + g * 16);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) wv[pp] = *(const f16x8 *)(wrow[pp] + (size_t)g * 512);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+                acc[pp][mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[pp], x[mf], acc[pp][mf], 0, 0, 0);
+    }
+    const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int v = m0 + mf * 32 + l31;
+        if (v < M) {
+            const uint32_t q1 = fdiv((uint32_t)v, divW);
+            const int x = v - (int)q1 * W;
+            const uint32_t q2 = fdiv(q1, divH);
+            const int y = (int)q1 - (int)q2 * H;
+            const uint32_t n = fdiv(q2, divD);
+            const int z = (int)q2 - (int)n * D;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int pos = wave * 2 + pp;
+                const int pa = pos >> 2, pb = (pos >> 1) & 1, pc = pos & 1;
+                _Float16 *o = out + ((((size_t)n * Do + 2 * z + pa) * Ho + 2 * y + pb) * Wo + 2 * x + pc) * Cout + nb * 32 + 4 * half;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f16x4 hv = {(_Float16)acc[pp][mf][4 * g4], (_Float16)acc[pp][mf][4 * g4 + 1],
+                                (_Float16)acc[pp][mf][4 * g4 + 2], (_Float16)acc[pp][mf][4 * g4 + 3]};
+                    *(f16x4 *)(o + 8 * g4) = hv;
+                }
+            }
+        }
+    }
+}
+
 // pack: [pos][cout block][g][lane][j 0..7]; cout = nb*32 + (lane&31), cin = g*16 + (lane>>5)*8 + j
 int tconv_weights_upload_f16(const float *w_host, int cin, int cout, TConvWeightsH *out) {
     MI355_REQUIRE(cin % 16 == 0 && cout % 32 == 0, "fp16 tconv %d->%d: need cin %% 16 == 0 and cout %% 32 == 0", cin, cout);
@@ -211,6 +360,15 @@ int tconv2_mfma_f16(const TConvWeightsH &w, const _Float16 *in, int N, int D, in
                     hipStream_t s) {
     const long M = (long)N * D * H * W;
     MI355_REQUIRE(M > 0 && M < (1l << 30), "tconv: %ld voxels out of range", M);
+    static int v1 = -1;
+    if (v1 < 0) { const char *e = getenv("MI355_TCONV_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
+    if (!v1) {
+        dim3 grid2((unsigned)((M + 127) / 128), w.cout / 32);
+        hipLaunchKernelGGL(tconv2_f16_mfma_v2_kernel, grid2, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cin, w.cout, D, H,
+                           W, make_fastdiv(W), make_fastdiv(H), make_fastdiv(D));
+        MI355_HIP(hipGetLastError());
+        return MI355_OK;
+    }
     constexpr int MF = 2;
     dim3 grid((unsigned)((M + 4 * MF * 32 - 1) / (4 * MF * 32)), 8 * (w.cout / 32));
     hipLaunchKernelGGL(tconv2_f16_mfma_kernel<MF>, grid, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cin, w.cout, D, H,
