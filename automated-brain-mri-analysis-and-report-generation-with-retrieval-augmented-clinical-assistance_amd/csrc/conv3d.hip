@@ -39,6 +39,9 @@ struct ConvArgs {
     int nchunks;
     int act;
     float slope;
+    const float *head_w, *head_b;  // fused 1x1x1 head (see ConvCall)
+    float *head_out;
+    int head_ncls;
 };
 
 // Shared epilogue.  The MFMAs are issued as D = W x X (weights are the A operand, voxels the B operand),
@@ -52,6 +55,48 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
                                               int ox0, int co_blk, float *red, bool sync_before_red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
+    if (p.head_out) {
+        // fused segmentation head: logits[k] = sum_cout w[k][cout] * act(conv[cout]) + b[k]; a lane holds 16*NF couts of
+        // its voxel, lanes l / l+32 the two halves -> one cross-half add; the feature map is never written
+        constexpr int KMAX = 4;
+        const int64_t Vo = (int64_t)p.Do * p.Ho * p.Wo;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int v = (wave * MF + mf) * 32 + l31;
+            const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
+            const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
+            float part[KMAX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co_blk + nf * 32 + 8 * g + 4 * half;
+                    const f32x4 bias = *(const f32x4 *)(p.bias + co);
+                    f32x4 x;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float y = acc[mf][nf][4 * g + k] + bias[k];
+                        if (p.act == ACT_LRELU) y = y > 0.f ? y : y * p.slope;
+                        x[k] = y;
+                    }
+#pragma unroll
+                    for (int c = 0; c < KMAX; ++c)
+                        if (c < p.head_ncls) {
+                            const f32x4 hw = *(const f32x4 *)(p.head_w + c * p.Cout + co);
+                            part[c] += x[0] * hw[0] + x[1] * hw[1] + x[2] * hw[2] + x[3] * hw[3];
+                        }
+                }
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) part[c] += __shfl_xor(part[c], 32);
+            if (ok && half == 0) {
+                const int64_t vi = ((int64_t)oz * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c)
+                    if (c < p.head_ncls) p.head_out[((int64_t)n * p.head_ncls + c) * Vo + vi] = part[c] + p.head_b[c];
+            }
+        }
+        return;
+    }
     float s1[NF][16], s2[NF][16];
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
@@ -640,6 +685,9 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
     ConvArgs a;
     a.in0 = c.in0; a.in1 = c.in1; a.C0 = c.C0; a.C1 = c.C1;
     a.wp = w.wp_dev; a.bias = w.bias_dev; a.out = c.out; a.stats = c.stats;
+    a.head_w = c.head_w; a.head_b = c.head_b; a.head_out = c.head_out; a.head_ncls = c.head_ncls;
+    MI355_REQUIRE(!c.head_out || (w.cout == 32 * w.nf && !c.stats && c.head_ncls >= 1 && c.head_ncls <= 4 && c.head_w && c.head_b),
+                  "fused head needs Cout (%d) == one workgroup's couts, no statistics, 1..4 classes", w.cout);
     a.N = c.N; a.Di = c.Di; a.Hi = c.Hi; a.Wi = c.Wi;
     const int st = w.stride;
     a.Do = (c.Di - 1) / st + 1; a.Ho = (c.Hi - 1) / st + 1; a.Wo = (c.Wi - 1) / st + 1;  // k=3, p=1

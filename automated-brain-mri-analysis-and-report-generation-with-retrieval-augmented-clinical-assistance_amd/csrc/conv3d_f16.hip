@@ -37,6 +37,9 @@ struct ConvArgsH {
     int act;
     float slope;
     int total_tiles;  // pipelined kernel
+    const float *head_w, *head_b;  // fused 1x1x1 head (see ConvCall)
+    float *head_out;
+    int head_ncls;
     int plane_bytes;  // brickvox * 16
 };
 
@@ -58,13 +61,54 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[MF][NF], const float
         }
 }
 
-template <int MF, int NF>
+template <int MF, int NF, bool HEAD = false>
 __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const ConvArgsH &p, int n, int oz0, int oy0,
                                                   int ox0, int co_blk, float *red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
     const bool lrelu = p.act == ACT_LRELU;
     const float slope = lrelu ? p.slope : 1.0f;  // max(x, 1*x) = x
+    if (HEAD) {
+        // fused segmentation head (see conv3d.hip): the accumulators already hold conv + bias
+        // (separate instantiation: carrying this path in the plain kernels costs them 220 B of spills)
+        constexpr int KMAX = 4;
+        const int64_t Vo = (int64_t)p.Do * p.Ho * p.Wo;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int v = (wave * MF + mf) * 32 + l31;
+            const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
+            const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
+            float part[KMAX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co_blk + nf * 32 + 8 * g + 4 * half;
+                    f32x4 x;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float y = acc[mf][nf][4 * g + k];
+                        // the unfused path rounds the activation to fp16 before the head reads it: keep that rounding
+                        x[k] = (float)(half_t)fmaxf(y, y * slope);
+                    }
+#pragma unroll
+                    for (int c = 0; c < KMAX; ++c)
+                        if (c < p.head_ncls) {
+                            const f32x4 hw = *(const f32x4 *)(p.head_w + c * p.Cout + co);
+                            part[c] += x[0] * hw[0] + x[1] * hw[1] + x[2] * hw[2] + x[3] * hw[3];
+                        }
+                }
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) part[c] += __shfl_xor(part[c], 32);
+            if (ok && half == 0) {
+                const int64_t vi = ((int64_t)oz * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c)
+                    if (c < p.head_ncls) p.head_out[((int64_t)n * p.head_ncls + c) * Vo + vi] = part[c] + p.head_b[c];
+            }
+        }
+        return;
+    }
     if (!p.stats) {
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
@@ -232,13 +276,13 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
 // ------------------------------------------------------------------ pipelined persistent kernel (stride 1)
 // ABL (timing experiments only, MI355_CONV_ABLATE): 1 = no voxel-fragment LDS reads, 2 = no weight fetches,
 // 4 = no staging of the next brick (results are then wrong; only the clock matters).
-template <int MF, int NF, int ABL = 0>
+template <int MF, int NF, int ABL = 0, bool HEAD = false>
 __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     constexpr int SLOTS = MF == 4 ? 11 : 8;  // 16-B staging pieces per thread and chunk
     constexpr int BD = 3;                    // weight fragments fetched BD tap-steps ahead; the ring phase must
                                              // be the same in every chunk, so BD divides 27
-    constexpr int FLIGHT = 10;               // tap-steps between a staging fetch and its LDS write
+    constexpr int FLIGHT = 7;               // tap-steps between a staging fetch and its LDS write
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
     const int IX = p.IX, IY = p.IY;
@@ -279,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
     // Tile-invariant part of every staging slot, computed once per kernel: the element offset of the piece
     // relative to the brick origin voxel (32-bit, per lane) and the brick faces it lies on (bit 0/1: z lo/hi,
     // 2/3: y, 4/5: x; -1 = unused slot).  Per chunk a fetch then costs one AND, one compare, one select.
-    int st_rel[SLOTS], st_face[SLOTS];
+    int st_pk[SLOTS];  // relative voxel offset (24 bits) | face bits << 24, or -1
     const int Cs0 = p.C0;  // relative offsets are kept for in0's channel stride; in1 (concat half) rescales below
 #pragma unroll
     for (int r = 0; r < SLOTS; ++r) {
@@ -289,10 +333,10 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         const int bx = bv - rr * IX;
         const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
         const int by = rr - bz * IY;
-        st_rel[r] = (bz * p.Hi + by) * p.Wi + bx;   // in voxels
-        st_face[r] = (i < npieces) ? ((bz == 0) | ((bz == p.IZ - 1) << 1) | ((by == 0) << 2) | ((by == IY - 1) << 3) |
-                                      ((bx == 0) << 4) | ((bx == IX - 1) << 5))
-                                   : -1;
+        const int rel = (bz * p.Hi + by) * p.Wi + bx;   // in voxels (< 2^24: checked on the host)
+        const int face = (bz == 0) | ((bz == p.IZ - 1) << 1) | ((by == 0) << 2) | ((by == IY - 1) << 3) | ((bx == 0) << 4) |
+                         ((bx == IX - 1) << 5);
+        st_pk[r] = (i < npieces) ? (rel | (face << 24)) : -1;
     }
     (void)Cs0;
     // which faces of the brick of tile tc stick out of the volume (wave-uniform)
@@ -311,22 +355,23 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
         const int i = r * 256 + tid;
-        const int face = st_face[r];
-        dst = (face >= 0) ? (i & 1) * p.plane_bytes + (i >> 1) * 16 : -1;
-        inside = (face >= 0) && ((face & faces) == 0);
+        const int pk = st_pk[r];
+        const int face = pk >> 24;  // -1 for an unused slot
+        dst = (pk >= 0) ? (i & 1) * p.plane_bytes + (i >> 1) * 16 : -1;
+        inside = (pk >= 0) && ((face & faces) == 0);
         if (ragged) {  // rare: tile overhangs the volume by more than the halo -> exact per-axis test
             const int bv = i >> 1;
             const int rr = (int)fdiv((uint32_t)bv, p.div_IX);
             const int bx = bv - rr * IX;
             const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
             const int by = rr - bz * IY;
-            inside = (face >= 0) && ((unsigned)(tc.oz0 - 1 + bz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + by) < (unsigned)p.Hi) &&
+            inside = (pk >= 0) && ((unsigned)(tc.oz0 - 1 + bz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + by) < (unsigned)p.Hi) &&
                      ((unsigned)(tc.ox0 - 1 + bx) < (unsigned)p.Wi);
         }
         // wave-uniform base of the brick origin voxel (may lie one voxel outside the tensor: only used when inside)
         const long base_vox = (((long)tc.n * p.Di + (tc.oz0 - 1)) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1);
         const half_t *sbase = src + base_vox * Csrc + coff;
-        const int rel = inside ? st_rel[r] * Csrc + qoff : 0;
+        const int rel = inside ? (pk & 0xffffff) * Csrc + qoff : 0;
         const half_t *ptr = inside ? sbase + rel : src;
         return *(const f32x4 *)ptr;
     };
@@ -413,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         __syncthreads();
 
         if (ch == p.nchunks - 1) {
-            conv_epilogue_f16<MF, NF>(acc, p, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red);
+            conv_epilogue_f16<MF, NF, HEAD>(acc, p, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red);
             acc_init_bias<MF, NF>(acc, p.bias, co_blk, half);
         }
         if (!have_next) break;
@@ -515,8 +560,11 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
     ConvArgsH a;
     a.in0 = c.in0; a.in1 = c.in1; a.C0 = c.C0; a.C1 = c.C1;
     a.wp = w.wp_dev; a.bias = w.bias_dev; a.out = c.out; a.stats = c.stats;
+    a.head_w = c.head_w; a.head_b = c.head_b; a.head_out = c.head_out; a.head_ncls = c.head_ncls;
     a.N = c.N; a.Di = c.Di; a.Hi = c.Hi; a.Wi = c.Wi;
     const int st = w.stride;
+    MI355_REQUIRE(!c.head_out || (st == 1 && use_pipe_h() && w.cout == 32 * w.nf && !c.stats && c.head_ncls >= 1 && c.head_ncls <= 4 && c.head_w && c.head_b),
+                  "fused head needs Cout (%d) == one workgroup's couts, no statistics, 1..4 classes", w.cout);
     a.Do = (c.Di - 1) / st + 1; a.Ho = (c.Hi - 1) / st + 1; a.Wo = (c.Wi - 1) / st + 1;
     a.Cout = w.cout;
     a.nchunks = w.cin_pad / 16;
@@ -535,6 +583,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         }
         MI355_REQUIRE(tiles < (1l << 30), "conv grid too large");
         MI355_REQUIRE(a.IX * a.IY * a.IZ <= (MF == 4 ? 11 : 8) * 128, "conv brick exceeds the staging slots");
+        MI355_REQUIRE((long)a.IZ * c.Hi * c.Wi < (1l << 24), "volume slab too large for the packed staging offsets");
         a.total_tiles = (int)tiles;
         const size_t lds_bytes = (size_t)4 * a.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float);
         MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
@@ -551,6 +600,12 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         if (MF == 4 && abl == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 4>, a, grid, lds_bytes, s, &attr[7]);
         if (MF == 4 && abl == 7) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 7>, a, grid, lds_bytes, s, &attr[7]);
         if (MF == 4 && abl == 6) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 6>, a, grid, lds_bytes, s, &attr[7]);
+        if (c.head_out) {
+            MI355_REQUIRE(w.nf == 1, "fused head: fp16 path supports Cout = 32 only");
+            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, 0, true>" : "conv3_f16_mfma_pipe_kernel<2, 1, 0, true>";
+            if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 0, true>, a, grid, lds_bytes, s, &attr[0]);
+            return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, 0, true>, a, grid, lds_bytes, s, &attr[1]);
+        }
         if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1>, a, grid, lds_bytes, s, &attr[0]);
         if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1>, a, grid, lds_bytes, s, &attr[1]);
         return launch_h(conv3_f16_mfma_pipe_kernel<2, 2>, a, grid, lds_bytes, s, &attr[2]);

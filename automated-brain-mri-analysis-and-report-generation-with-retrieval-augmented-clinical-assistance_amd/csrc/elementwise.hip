@@ -324,6 +324,71 @@ int head_aggregate(const HeadWeights &w, const void *feat, int dtype, int first_
     return MI355_OK;
 }
 
+// Same as head_aggregate_kernel when the last conv already applied the head (logits [n_mirrors][ncls][PV] of this tile).
+__global__ void logits_aggregate_kernel(const float *logits, int ncls, MirrorList ml, int P0, int P1, int P2, int nonlin,
+                                        const float *gauss, float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0,
+                                        int x0) {
+    const int64_t PV = (int64_t)P0 * P1 * P2;
+    const int64_t ZYXp = (int64_t)Zp * Yp * Xp;
+    const float mult = 1.0f / (float)ml.n;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < PV; v += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(v % P2);
+        const int py = (int)((v / P2) % P1);
+        const int pz = (int)(v / ((int64_t)P2 * P1));
+        float res[HEAD_MAX_CLS];
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_CLS; ++k) res[k] = 0.f;
+        for (int mi = 0; mi < ml.n; ++mi) {
+            const int m = ml.m[mi];
+            const int sz = (m & 1) ? P0 - 1 - pz : pz;
+            const int sy = (m & 2) ? P1 - 1 - py : py;
+            const int sx = (m & 4) ? P2 - 1 - px : px;
+            const int64_t sv = ((int64_t)sz * P1 + sy) * P2 + sx;
+            float lg[HEAD_MAX_CLS];
+#pragma unroll
+            for (int k = 0; k < HEAD_MAX_CLS; ++k) lg[k] = (k < ncls) ? logits[((int64_t)mi * ncls + k) * PV + sv] : 0.f;
+            if (nonlin == MI355_NONLIN_SIGMOID) {
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) lg[k] = 1.0f / (1.0f + expf(-lg[k]));
+            } else if (nonlin == MI355_NONLIN_SOFTMAX) {
+                float mx = lg[0];
+#pragma unroll
+                for (int k = 1; k < HEAD_MAX_CLS; ++k) if (k < ncls) mx = fmaxf(mx, lg[k]);
+                float den = 0.f;
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) { lg[k] = expf(lg[k] - mx); den += lg[k]; }
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) lg[k] = lg[k] / den;
+            }
+#pragma unroll
+            for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) res[k] += mult * lg[k];
+        }
+        const float g = gauss ? gauss[v] : 1.0f;
+        const int64_t gi = ((int64_t)(z0 + pz) * Yp + (y0 + py)) * Xp + (x0 + px);
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_CLS; ++k)
+            if (k < ncls) agg[k * ZYXp + gi] += res[k] * g;
+        if (cnt) cnt[gi] += g;
+    }
+}
+
+int logits_aggregate(const float *logits, int ncls, int first_sample, const int *mirrors_host, int n_mirrors, int P0, int P1,
+                     int P2, int nonlin, const float *gauss, float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0,
+                     int x0, hipStream_t s) {
+    MI355_REQUIRE(n_mirrors >= 1 && n_mirrors <= 8 && ncls >= 1 && ncls <= HEAD_MAX_CLS, "logits_aggregate: bad arguments");
+    MirrorList ml;
+    ml.n = n_mirrors;
+    for (int i = 0; i < 8; ++i) ml.m[i] = i < n_mirrors ? mirrors_host[i] : 0;
+    const int64_t PV = (int64_t)P0 * P1 * P2;
+    int64_t blocks = (PV + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(logits_aggregate_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       logits + (size_t)first_sample * ncls * PV, ncls, ml, P0, P1, P2, nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0,
+                       y0, x0);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
 // class_probabilities = aggregated / normaliser, cropped back from the padded grid.
 __global__ void finish_probs_kernel(const float *agg, const float *cnt, int C, int Z, int Y, int X, int Zp,
                                     int Yp, int Xp, int pz, int py, int px, float *probs, int accumulate) {

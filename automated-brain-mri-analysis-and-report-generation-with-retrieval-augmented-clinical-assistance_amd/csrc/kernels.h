@@ -35,6 +35,11 @@ struct ConvCall {
     double *stats = nullptr;  // [N][Cout][2] (sum, sum of squares) accumulated when non-null
     int act = ACT_NONE;
     float slope = 0.01f;
+    // fused 1x1x1 segmentation head (last decoder conv, Cout = one workgroup's couts): when head_out is set the
+    // feature map is NOT stored; logits [N][ncls][Vo] fp32 = head_w [ncls][Cout] . act(conv) + head_b are
+    const float *head_w = nullptr, *head_b = nullptr;
+    float *head_out = nullptr;
+    int head_ncls = 0;
 };
 int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name = nullptr);
 int conv3d_direct_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s);
@@ -56,6 +61,9 @@ struct ConvCallH {
     double *stats = nullptr;
     int act = ACT_NONE;
     float slope = 0.01f;
+    const float *head_w = nullptr, *head_b = nullptr;  // fused segmentation head, see ConvCall
+    float *head_out = nullptr;
+    int head_ncls = 0;
 };
 int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, const char **kernel_name = nullptr);
 
@@ -113,6 +121,10 @@ int head_logits(const HeadWeights &w, const void *feat, int dtype, int N, int64_
 int head_aggregate(const HeadWeights &w, const void *feat, int dtype, int first_sample, const int *mirrors_host,
                    int n_mirrors, int P0, int P1, int P2, int nonlin, const float *gauss, float *agg,
                    float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, hipStream_t s);
+// same as head_aggregate for forwards whose last conv already produced logits [n_samples][ncls][PV]
+int logits_aggregate(const float *logits, int ncls, int first_sample, const int *mirrors_host, int n_mirrors, int P0, int P1,
+                     int P2, int nonlin, const float *gauss, float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0,
+                     int x0, hipStream_t s);
 // probs[c][z][y][x] (+)= agg[c][z+pz][y+py][x+px] / cnt[...]; then optional scale (fold mean)
 int finish_probs(const float *agg, const float *cnt, int C, int Z, int Y, int X, int Zp, int Yp, int Xp,
                  int pz, int py, int px, float *probs, int accumulate, hipStream_t s);

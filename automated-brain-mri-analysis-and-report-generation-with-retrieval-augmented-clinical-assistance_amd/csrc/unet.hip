@@ -8,6 +8,7 @@
 //     sliding_window / _get_gaussian / _internal_maybe_mirror_and_pred_3D (un-vendored upstream;
 //     SURVEY.md 8a rows T1-T5) as driven by run_brats2021_inference_singlethread.py:97-128.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -225,7 +226,8 @@ static std::string conv_kernel_name(const ConvWeights &w) {
 
 // One ConvDropoutNormNonlin / ConvDropoutNonlinNorm block.
 static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const void *in0, int C0,
-                     const void *in1, int C1, int N, int Di, int Hi, int Wi, void *out, hipStream_t s) {
+                     const void *in1, int C1, int N, int Di, int Hi, int Wi, void *out, hipStream_t s,
+                     float *head_logits_out = nullptr) {
     const bool f16 = net->dtype == MI355_F16;
     double *stats = (double *)(net->arena + pl.stats_off);
     float *scale = (float *)(net->arena + pl.scale_off), *shift = (float *)(net->arena + pl.shift_off);
@@ -248,6 +250,7 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
             c.in0 = (const _Float16 *)in0; c.in1 = (const _Float16 *)in1; c.C0 = C0; c.C1 = C1;
             c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi; c.out = (_Float16 *)out; c.slope = net->slope;
             c.act = act; c.stats = stats_arg;
+            if (head_logits_out) { c.head_w = net->head.w_dev; c.head_b = net->head.b_dev; c.head_ncls = net->head.ncls; c.head_out = head_logits_out; }
             const char *kname = nullptr;
             ProfScope ps(net, s, "conv3_f16", flops, bytes);
             MI355_TRY(conv3d_mfma_f16(L.wh, c, s, &kname));
@@ -257,6 +260,7 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
             c.in0 = (const float *)in0; c.in1 = (const float *)in1; c.C0 = C0; c.C1 = C1;
             c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi; c.out = (float *)out; c.slope = net->slope;
             c.act = act; c.stats = stats_arg;
+            if (head_logits_out) { c.head_w = net->head.w_dev; c.head_b = net->head.b_dev; c.head_ncls = net->head.ncls; c.head_out = head_logits_out; }
             const char *kname = nullptr;
             ProfScope ps(net, s, conv_kernel_name(L.w), flops, bytes);
             if (L.w.wp_dev) MI355_TRY(conv3d_mfma_f32(L.w, c, s, &kname));
@@ -280,8 +284,11 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
 }
 
 // x0: [N,D,H,W,cin_pad] already in the arena at pl.x0_off.  Returns the last decoder feature map.
+// If the last decoder block has no run-time normalisation (BN folded / no norm) and its Cout fits one workgroup, the
+// 1x1x1 head is fused into its epilogue: *is_logits = true and *feat points at fp32 logits [N][ncls][V] (written to
+// logits_target when given, else into the arena); the 32-channel feature map is then never written nor re-read.
 static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H, int W, const void **feat,
-                            int *feat_c, hipStream_t s) {
+                            int *feat_c, hipStream_t s, bool *is_logits = nullptr, float *logits_target = nullptr) {
     const int np = net->num_pool;
     const bool f16 = net->dtype == MI355_F16;
     auto buf = [&](int k, int l) { return (void *)(net->arena + pl.off[k][l]); };
@@ -325,11 +332,29 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
         for (size_t i = 0; i < net->dec[u].size(); ++i) {
             const ConvLayer &L = net->dec[u][i];
             void *out = (i & 1) ? freeAB : buf(3, l);
+            static int fuse = -1;
+            if (fuse < 0) {
+                const char *e = getenv("MI355_FUSE_HEAD"), *ci = getenv("MI355_CONV_IMPL");
+                fuse = (e && e[0] == '0') ? 0 : 1;
+                if (f16 && ci && ci[0] == '0') fuse = 0;  // the fp16 fused epilogue exists in the pipelined kernel only
+            }
+            const bool last = is_logits && (u == np - 1) && (i + 1 == net->dec[u].size());
+            const int lnf = f16 ? L.wh.nf : L.w.nf;
+            const bool has_pack = f16 ? (L.wh.wp_dev != nullptr) : (L.w.wp_dev != nullptr);
+            if (last && fuse && !L.runtime_norm && !L.post_affine && has_pack && L.cout == 32 * lnf && net->head.ncls <= 4 &&
+                net->head.cin == L.cout && (!f16 || lnf == 1)) {
+                float *lg = logits_target ? logits_target : (float *)out;
+                MI355_TRY(run_block(net, pl, L, in0, C0, in1, C1, N, Dl, Hl, Wl, nullptr, s, lg));
+                *is_logits = true;
+                *feat = lg; *feat_c = net->head.ncls;
+                return MI355_OK;
+            }
             MI355_TRY(run_block(net, pl, L, in0, C0, in1, C1, N, Dl, Hl, Wl, out, s));
             in0 = out; C0 = L.cout; in1 = nullptr; C1 = 0;
         }
         cur = in0; curC = C0;
     }
+    if (is_logits) *is_logits = false;
     *feat = cur; *feat_c = curC;
     return MI355_OK;
 }
@@ -455,12 +480,19 @@ static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X,
                                 (int)samples.size(), g.P[0], g.P[1], g.P[2], net->cin_pad,
                                 (void *)(net->arena + pl.x0_off), net->dtype, s));
         }
-        const void *feat; int fc;
-        MI355_TRY(forward_features(net, pl, (int)samples.size(), g.P[0], g.P[1], g.P[2], &feat, &fc, s));
-        MI355_REQUIRE(fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
+        const void *feat; int fc; bool is_logits = false;
+        MI355_TRY(forward_features(net, pl, (int)samples.size(), g.P[0], g.P[1], g.P[2], &feat, &fc, s, &is_logits));
+        MI355_REQUIRE(is_logits || fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
         for (int i = 0; i < nb; ++i) {
             const TileDesc &td = g.tiles[mine[b0 + i]];
             const double pv = (double)g.P[0] * g.P[1] * g.P[2];
+            if (is_logits) {
+                ProfScope ps(net, s, "logits_aggregate_kernel", 0.0, 4.0 * pv * (nm * net->num_classes + 2.0 * net->num_classes + 3.0));
+                MI355_TRY(logits_aggregate((const float *)feat, net->num_classes, i * nm, g.mirrors.data(), nm, g.P[0], g.P[1], g.P[2],
+                                           o.nonlin, use_gauss ? net->gauss_dev : nullptr, agg, (cnt && world == 1) ? cnt : nullptr,
+                                           g.Zp[0], g.Zp[1], g.Zp[2], td.z0, td.y0, td.x0, s));
+                continue;
+            }
             ProfScope ps(net, s, "head_aggregate_kernel", 2.0 * pv * nm * fc * net->num_classes,
                          pv * ((net->dtype == MI355_F16 ? 2.0 : 4.0) * nm * fc + 4.0 * (2.0 * net->num_classes + 3.0)));
             MI355_TRY(head_aggregate(net->head, feat, net->dtype, i * nm, g.mirrors.data(), nm, g.P[0], g.P[1], g.P[2], o.nonlin,
@@ -580,8 +612,9 @@ extern "C" int mi355_unet_forward(mi355_unet_t net, const float *x_dev, int n, i
     MI355_TRY(ensure_arena(net, pl.total));
     const int64_t V = (int64_t)d * h * w;
     MI355_TRY(nchw_to_ndhwc(x_dev, n, net->in_channels, V, net->cin_pad, (void *)(net->arena + pl.x0_off), net->dtype, s));
-    const void *feat; int fc;
-    MI355_TRY(forward_features(net, pl, n, d, h, w, &feat, &fc, s));
+    const void *feat; int fc; bool is_logits = false;
+    MI355_TRY(forward_features(net, pl, n, d, h, w, &feat, &fc, s, &is_logits, logits_dev));
+    if (is_logits) return MI355_OK;  // the last conv wrote [n][ncls][V] straight into logits_dev
     MI355_REQUIRE(fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
     MI355_TRY(head_logits(net->head, feat, net->dtype, n, V, logits_dev, s));
     return MI355_OK;
