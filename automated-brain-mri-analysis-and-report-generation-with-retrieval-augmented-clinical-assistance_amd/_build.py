@@ -1,16 +1,23 @@
-"""Builds the gfx950 shared library (C ABI, no torch dependency) in-tree with hipcc."""
+"""Builds the gfx950 shared library (C ABI, no torch dependency) in-tree with hipcc.
+
+Each ``csrc/*.hip`` is compiled to an object file in parallel (``hipcc -c``), then linked into
+``lib/libmi355_nnunet.so``; objects are rebuilt only when their source or a header changed.
+"""
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
+OBJ_DIR = LIB_DIR / "obj"
 LIB_PATH = LIB_DIR / "libmi355_nnunet.so"
 SOURCES = ["conv3d.hip", "conv3d_f16.hip", "tconv.hip", "elementwise.hip", "extras.hip", "unet.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-pass-failed"]
 
 
 def find_hipcc() -> str:
@@ -20,29 +27,48 @@ def find_hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def _headers():
+    return list(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "mi355_nnunet.h"]
+
+
 def needs_build() -> bool:
     if not LIB_PATH.exists():
         return True
     t = LIB_PATH.stat().st_mtime
-    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "mi355_nnunet.h"]
+    deps = [CSRC / s for s in SOURCES] + _headers()
     return any(p.stat().st_mtime > t for p in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 -shared: cross-compiles without a GPU."""
-    if not force and not needs_build():
-        return LIB_PATH
-    LIB_DIR.mkdir(exist_ok=True)
-    cmd = [find_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-result", "-Wno-pass-failed"]
-    cmd += [str(CSRC / s) for s in SOURCES]
-    tmp = LIB_PATH.with_suffix(".so.tmp")
-    cmd += ["-o", str(tmp)]
+def _compile(hipcc: str, src: Path, obj: Path, verbose: bool):
+    cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError(f"hipcc failed on {src.name}:\n" + res.stdout + res.stderr)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950: cross-compiles without a GPU."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = find_hipcc()
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    hdr_time = max(p.stat().st_mtime for p in _headers())
+    jobs = []
+    for s in SOURCES:
+        src, obj = CSRC / s, OBJ_DIR / (s + ".o")
+        if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_time):
+            jobs.append((src, obj))
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
+        list(pool.map(lambda j: _compile(hipcc, j[0], j[1], verbose), jobs))
+    tmp = LIB_PATH.with_suffix(".so.tmp")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(OBJ_DIR / (s + ".o")) for s in SOURCES], "-o", str(tmp)]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 

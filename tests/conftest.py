@@ -14,6 +14,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def amd():
+    """The product package; compiles the HIP library first if it is missing or stale (hipcc cross-compiles
+    without a GPU, and the GPU box has the same toolchain)."""
+    import importlib
+    build = importlib.import_module(
+        "automated-brain-mri-analysis-and-report-generation-with-retrieval-augmented-clinical-assistance_amd._build")
+    build.build()
     import brats_amd
     return brats_amd
 
