@@ -151,23 +151,38 @@ def main():
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample of the same workload
     cpu = None
+    parity = None
     if not args.no_cpu_baseline and world == 1:
-        from oracle import unet_ref
+        from oracle import unet_ref, tiler_ref
         sd, meta = synthetic.make_model(models[0][0], seed=models[0][1])
         cfg = unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])
-        x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 4) + patch).astype(np.float32))
+        # the sample is a REAL tile of this step's volume (first tile of the sliding window), so the timed CPU
+        # forwards double as the parity check of the GPU path on the same input
+        z0, y0, x0 = steps_tbl[0][0], steps_tbl[1][0], steps_tbl[2][0]
+        tile = data[:, z0:z0 + patch[0], y0:y0 + patch[1], x0:x0 + patch[2]]
+        pad = [patch[i] - tile.shape[1 + i] for i in range(3)]
+        tile = torch.nn.functional.pad(tile, (0, pad[2], 0, pad[1], 0, pad[0]))[None].contiguous()
+        x = tile.cpu()
         cores = torch.get_num_threads()
         unet_ref.unet_forward(sd, x[:, :, :64, :64, :64], cfg)  # page in
         n_fw = 0
         tc0 = time.perf_counter()
+        ref_logits = None
         while n_fw < 2 or (time.perf_counter() - tc0 < 10.0 and n_fw < 6):
-            unet_ref.unet_forward(sd, x, cfg)
+            ref_logits = unet_ref.unet_forward(sd, x, cfg)
             n_fw += 1
         per_fw = (time.perf_counter() - tc0) / n_fw
         cpu_flops_model0 = nets[0].flops(patch)
         est_volume_s = per_fw * flops_per_volume / cpu_flops_model0
+        got_logits = nets[0](tile).cpu()
+        pr, pg = torch.sigmoid(ref_logits)[0].numpy(), torch.sigmoid(got_logits)[0].numpy()
+        dice_tile = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(pg), tiler_ref.regions_to_labels(pr))
+        parity = dict(sample="first 128^3 tile of the timed volume, GPU forward vs the CPU oracle forward",
+                      max_abs_prob_err=float(np.abs(pg - pr).max()),
+                      max_abs_logit_err=float((got_logits - ref_logits).abs().max()), logit_std=float(ref_logits.std()),
+                      dice_wt_tc_et_mean=round(dice_tile["mean"], 6))
         cpu = dict(value=round(1.0 / est_volume_s, 6), unit="volumes/s", cores=cores, kind="port",
-                   sample=f"{n_fw} forwards of model {models[0][0]} on one 1x4x128^3 patch with the torch-CPU fp32 oracle "
+                   sample=f"{n_fw} forwards of model {models[0][0]} on the first 1x4x128^3 tile of the timed volume with the torch-CPU fp32 oracle "
                           f"({per_fw:.2f} s each), scaled by flops to the {n_tiles * n_mirrors * len(nets)} forwards of one volume",
                    seconds_per_volume_est=round(est_volume_s, 2))
 
@@ -181,7 +196,7 @@ def main():
                    "models": [m[0] for m in models], "crop": list(data.shape[1:]), "sharding": "cases (one volume per rank per step)",
                    "tflop_per_volume": round(flops_per_volume / 1e12, 3)},
         "sustained_tflops_per_gpu": round(flops_per_volume * args.steps / elapsed / 1e12, 2),
-        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_ref": parity, "kernels": kernels,
         "label_histogram": label_hist,
         "speedup_vs_nominal_5min": round(300.0 / (elapsed / args.steps), 1),
     }

@@ -176,3 +176,49 @@ def test_sliding_window_f16_tta(amd, gpu):
     assert np.abs(got - ref).max() <= 5e-2
     d = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(got), tiler_ref.regions_to_labels(ref))
     assert d["mean"] >= 0.995
+
+
+# --------------------------------------------------------------------------- full BASELINE size
+def test_full_size_config2_properties_and_oracle_tiles(amd, gpu):
+    """BASELINE.json configs[1] at full size (4x155x240x240 synthetic case, model A, 128^3 tiles, no TTA):
+    size-independent properties of the whole path + the CPU oracle on two of the eight tiles."""
+    sd, meta = amd.synthetic.make_model("A", seed=7)
+    net = amd.UNet(sd, norm="batch")
+    raw = amd.synthetic.make_volume(seed=1000)
+    data, props = amd.preprocessing.preprocess_case(raw)
+    patch = (128, 128, 128)
+    kw = dict(patch_size=patch, step_size=0.5, do_mirroring=False, use_gaussian=True, nonlin="sigmoid")
+    p1 = amd.predictor.predict_folds([net], data, **kw)
+    assert p1.shape == (3,) + tuple(data.shape[1:]) and bool(torch.isfinite(p1).all())
+    assert float(p1.min()) >= 0.0 and float(p1.max()) <= 1.0
+    # (1) determinism: a second run is bit-identical (no atomics on the BN-folded path)
+    assert torch.equal(amd.predictor.predict_folds([net], data, **kw), p1)
+    # (2) batching invariance: one tile per forward instead of eight
+    p_b1 = amd.predictor.predict_folds([net], data, batch_tiles=1, **kw)
+    assert float((p_b1 - p1).abs().max()) <= 5e-5
+    # (3) mirror equivariance of the whole sliding window: flipping the volume along x and predicting with the
+    #     x-mirror-only TTA schedule visits the same forwards -> probabilities are the flipped ones.  Uniform
+    #     tile weights here: nnU-Net's Gaussian is centred on index patch//2 = 64 of 128, i.e. not mirror-symmetric
+    kw_tta = dict(kw, do_mirroring=True, mirror_axes=(2,), use_gaussian=False)
+    pa = amd.predictor.predict_folds([net], data, **kw_tta)
+    pb = amd.predictor.predict_folds([net], torch.flip(data, (3,)).contiguous(), **kw_tta)
+    assert float((torch.flip(pb, (3,)) - pa).abs().max()) <= 2e-4
+    # (4) labels, pasted into the raw-size volume
+    lo = [b[0] for b in props["crop_bbox"]]
+    seg = amd.ops.regions_to_labels(p1, (1, 2, 3), lo, props["original_size_of_raw_data"]).cpu().numpy()
+    assert seg.shape == (155, 240, 240) and set(np.unique(seg)) <= {0, 1, 2, 3}
+    outside = np.ones_like(seg, dtype=bool)
+    outside[tuple(slice(b[0], b[1]) for b in props["crop_bbox"])] = False
+    assert not seg[outside].any()
+    # (5) CPU oracle on the first and the last tile of the step table (2 x ~4 s of CPU forwards)
+    cfg = unet_ref.default_cfg("batch")
+    host = data.cpu().numpy()
+    steps = tiler_ref.compute_steps_for_sliding_window(patch, host.shape[1:], 0.5)
+    for z0, y0, x0 in ((steps[0][0], steps[1][0], steps[2][0]), (steps[0][-1], steps[1][-1], steps[2][-1])):
+        tile = np.ascontiguousarray(host[None, :, z0:z0 + 128, y0:y0 + 128, x0:x0 + 128])
+        ref = unet_ref.unet_forward(sd, tile, cfg).numpy()
+        got = net(torch.from_numpy(tile).to(gpu)).cpu().numpy()
+        _check_logits(got, ref)
+        d = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(1 / (1 + np.exp(-got[0]))),
+                                        tiler_ref.regions_to_labels(1 / (1 + np.exp(-ref[0]))))
+        assert d["mean"] >= 0.999
