@@ -1,0 +1,275 @@
+// First convolution of the network (Cin <= 4, 3x3x3, stride 1): the x-taps are folded into the GEMM K dimension.
+//
+// With only 4 input channels a tap-by-tap implicit GEMM wastes the matrix cores (K per tap = 4, padded to 8 in
+// fp32 and to 16 in fp16).  Here K = (dx, channel): the NDHW4 layout makes the 3 x-neighbours of a voxel contiguous
+// in memory and in the LDS brick, so for every (dz, dy)
+//   fp32: three 8-B LDS reads feed 6 MFMAs 32x32x2   (lane half h holds channels 2h, 2h+1 of voxel x+dx)
+//   fp16: two 8-B LDS reads feed ONE MFMA 32x32x16   (lane half 0: voxels x, x+1; half 1: voxel x+2 + 4 zero-weight k)
+// i.e. 54 instead of 108 MFMAs (fp32) and 9 instead of 27 (fp16) per 32-voxel fragment, on an input tensor of
+// 16 B / 8 B per voxel instead of 32 B.  All 27 / 9 weight fragments of a 32-cout block live in registers.
+// Same D = W x X orientation and epilogues as conv3d.hip / conv3d_f16.hip (reference generic_UNet.py:56,69).
+#include "kernels.h"
+
+#include <vector>
+
+namespace mi355 {
+
+struct StemArgs {
+    const void *in;     // [N,D,H,W,4] (fp32 or fp16)
+    const void *wp;     // packed weights
+    const float *bias;
+    void *out;          // [N,D,H,W,Cout]
+    double *stats;
+    int N, D, H, W, Cout;
+    int tiles_x, tiles_y, tiles_z;
+    FastDiv div_tiles_per_n, div_tiles_x, div_tiles_y;
+    int act;
+    float slope;
+};
+
+// tile 4 x 4 x 32 outputs (wave = z, fragment = y), brick 6 x 6 x 34 (+2 voxels of x padding for the fp16 reads)
+constexpr int S_IX = 36, S_IY = 6, S_IZ = 6;
+constexpr int S_BRICK = S_IX * S_IY * S_IZ;
+
+template <typename T>
+__device__ __forceinline__ void stem_stage(const T *in, char *lds, int n, int D, int H, int W, int oz0, int oy0, int ox0) {
+    // one piece per voxel: 4 channels = 16 B (fp32) / 8 B (fp16)
+    constexpr int PB = 4 * sizeof(T);
+    for (int i = threadIdx.x; i < S_BRICK; i += 256) {
+        const int r = i / S_IX, bx = i - r * S_IX;
+        const int bz = r / S_IY, by = r - bz * S_IY;
+        const int iz = oz0 - 1 + bz, iy = oy0 - 1 + by, ix = ox0 - 1 + bx;
+        const bool ok = ((unsigned)iz < (unsigned)D) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+        const size_t off = ok ? ((((size_t)n * D + iz) * H + iy) * W + ix) * 4 : 0;
+        if (sizeof(T) == 4) {
+            f32x4 v = *(const f32x4 *)((const float *)in + off);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *(f32x4 *)(lds + (size_t)i * PB) = ok ? v : z;
+        } else {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 v = *(const f32x2 *)((const _Float16 *)in + off);
+            const f32x2 z = {0.f, 0.f};
+            *(f32x2 *)(lds + (size_t)i * PB) = ok ? v : z;
+        }
+    }
+}
+
+__device__ __forceinline__ void stem_tile(const StemArgs &p, int &n, int &oz0, int &oy0, int &ox0) {
+    const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    n = (int)fdiv((uint32_t)bid, p.div_tiles_per_n);
+    const int t = bid - n * (int)p.div_tiles_per_n.d;
+    const int tzy = (int)fdiv((uint32_t)t, p.div_tiles_x);
+    const int tile_x = t - tzy * p.tiles_x;
+    const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
+    const int tile_y = tzy - tile_z * p.tiles_y;
+    oz0 = tile_z << 2; oy0 = tile_y << 2; ox0 = tile_x << 5;
+}
+
+// Epilogue for the fixed 4x4x32 tile: lane = voxel (x = lane&31, y = fragment, z = wave), 16 couts per lane.
+template <typename T>
+__device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &p, int n, int oz0, int oy0, int ox0,
+                                              int co_blk, float *red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    float s1[16], s2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    const float slope = p.act == ACT_LRELU ? p.slope : 1.0f;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int oz = oz0 + wave, oy = oy0 + mf, ox = ox0 + l31;
+        const bool ok = (oz < p.D) && (oy < p.H) && (ox < p.W);
+        T *orow = (T *)p.out + ((((size_t)n * p.D + oz) * p.H + oy) * p.W + ox) * p.Cout + co_blk + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bias = *(const f32x4 *)(p.bias + co_blk + 8 * g + 4 * half);
+            f32x4 val;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x = acc[mf][4 * g + k] + bias[k];
+                x = fmaxf(x, x * slope);
+                val[k] = x;
+                if (ok && p.stats) { s1[4 * g + k] += x; s2[4 * g + k] += x * x; }
+            }
+            if (ok) {
+                if (sizeof(T) == 4) *(f32x4 *)(orow + 8 * g) = val;
+                else {
+                    f16x4 hv = {(_Float16)val[0], (_Float16)val[1], (_Float16)val[2], (_Float16)val[3]};
+                    *(f16x4 *)(orow + 8 * g) = hv;
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();  // the brick is dead: reuse it for the cross-wave reduction
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = s1[r], b = s2[r];
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+            if (l31 == 0) {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[(wave * 32 + c) * 2 + 0] = a;
+                red[(wave * 32 + c) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int c = tid >> 1, k = tid & 1;
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tot += (double)red[(w * 32 + c) * 2 + k];
+            atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, tot);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- fp32
+// weights: [cout block][tap 27][lane 64][2]: lane (cout = l&31, h = l>>5) holds W[cout][c = 2h + j][tap], j = 0, 1
+__global__ __launch_bounds__(256, 3) void conv3_stem_f32_kernel(StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    int n, oz0, oy0, ox0;
+    stem_tile(p, n, oz0, oy0, ox0);
+    const int co_blk = (int)blockIdx.y * 32;
+    f32x2 wreg[27];
+    const f32x2 *wsrc = (const f32x2 *)p.wp + (size_t)blockIdx.y * 27 * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) wreg[t] = wsrc[t * 64];
+    stem_stage<float>((const float *)p.in, lds, n, p.D, p.H, p.W, oz0, oy0, ox0);
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mf][r] = 0.f;
+    // lane's voxel at tap (0,0,0): brick (z = wave, y = mf, x = l31); 16 B per voxel, half h reads channels 2h, 2h+1
+    const int base = ((wave * S_IY) * S_IX + l31) * 16 + half * 8;
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            f32x2 a[4][3];
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    a[mf][dx] = *(const f32x2 *)(lds + base + (((dz * S_IY) + dy + mf) * S_IX + dx) * 16);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf)
+                        acc[mf] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[(dz * 3 + dy) * 3 + dx][j], a[mf][dx][j], acc[mf], 0, 0, 0);
+        }
+    stem_epilogue<float>(acc, p, n, oz0, oy0, ox0, co_blk, (float *)lds);
+}
+
+// ---------------------------------------------------------------- fp16
+// weights: [cout block][(dz,dy) 9][lane 64][8 halfs]: lane (cout, h): h = 0 -> W[c0..3][dx0], W[c0..3][dx1];
+// h = 1 -> W[c0..3][dx2], 0, 0, 0, 0
+__global__ __launch_bounds__(256, 3) void conv3_stem_f16_kernel(StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    int n, oz0, oy0, ox0;
+    stem_tile(p, n, oz0, oy0, ox0);
+    const int co_blk = (int)blockIdx.y * 32;
+    f16x8 wreg[9];
+    const f16x8 *wsrc = (const f16x8 *)p.wp + (size_t)blockIdx.y * 9 * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wreg[t] = wsrc[t * 64];
+    stem_stage<_Float16>((const _Float16 *)p.in, lds, n, p.D, p.H, p.W, oz0, oy0, ox0);
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mf][r] = 0.f;
+    // 8 B per voxel; half h starts at voxel x + 2h and reads 16 B (two 8-B reads: the address is only 8-B aligned)
+    const int base = ((wave * S_IY) * S_IX + l31 + 2 * half) * 8;
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const char *ptr = lds + base + ((dz * S_IY) + dy + mf) * S_IX * 8;
+                const f16x4 lo = *(const f16x4 *)ptr, hi = *(const f16x4 *)(ptr + 8);
+                const f16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc[mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[dz * 3 + dy], a, acc[mf], 0, 0, 0);
+            }
+        }
+    stem_epilogue<_Float16>(acc, p, n, oz0, oy0, ox0, co_blk, (float *)lds);
+}
+
+// ---------------------------------------------------------------- host
+int stem_weights_upload(const float *w_host, const float *bias_host, int cin, int cout, int dtype, StemWeights *out) {
+    MI355_REQUIRE(cin >= 1 && cin <= 4 && cout % 32 == 0, "stem conv: need cin <= 4 and cout %% 32 == 0 (got %d -> %d)", cin, cout);
+    StemWeights sw;
+    sw.cin = cin; sw.cout = cout; sw.dtype = dtype;
+    const int nblk = cout / 32;
+    auto W = [&](int co, int c, int tap) { return c < cin ? w_host[((size_t)co * cin + c) * 27 + tap] : 0.f; };
+    if (dtype == MI355_F16) {
+        std::vector<_Float16> packed((size_t)nblk * 9 * 64 * 8);
+        size_t o = 0;
+        for (int b = 0; b < nblk; ++b)
+            for (int zy = 0; zy < 9; ++zy)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j, ++o) {
+                        const int co = b * 32 + (lane & 31), h = lane >> 5;
+                        const int k = 8 * h + j, dx = k >> 2, c = k & 3;
+                        packed[o] = (_Float16)(dx < 3 ? W(co, c, zy * 3 + dx) : 0.f);
+                    }
+        MI355_HIP(hipMalloc(&sw.wp_dev, packed.size() * sizeof(_Float16)));
+        MI355_HIP(hipMemcpy(sw.wp_dev, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> packed((size_t)nblk * 27 * 64 * 2);
+        size_t o = 0;
+        for (int b = 0; b < nblk; ++b)
+            for (int tap = 0; tap < 27; ++tap)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 2; ++j, ++o) {
+                        const int co = b * 32 + (lane & 31), h = lane >> 5;
+                        packed[o] = W(co, 2 * h + j, tap);
+                    }
+        MI355_HIP(hipMalloc(&sw.wp_dev, packed.size() * sizeof(float)));
+        MI355_HIP(hipMemcpy(sw.wp_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    MI355_HIP(hipMalloc(&sw.bias_dev, cout * sizeof(float)));
+    if (bias_host) MI355_HIP(hipMemcpy(sw.bias_dev, bias_host, cout * sizeof(float), hipMemcpyHostToDevice));
+    else MI355_HIP(hipMemset(sw.bias_dev, 0, cout * sizeof(float)));
+    *out = sw;
+    return MI355_OK;
+}
+
+void stem_weights_free(StemWeights *w) {
+    if (w->wp_dev) (void)hipFree(w->wp_dev);
+    if (w->bias_dev) (void)hipFree(w->bias_dev);
+    *w = StemWeights();
+}
+
+int conv3d_stem(const StemWeights &w, const void *in, int N, int D, int H, int W, void *out, double *stats, int act,
+                float slope, hipStream_t s) {
+    StemArgs a;
+    a.in = in; a.wp = w.wp_dev; a.bias = w.bias_dev; a.out = out; a.stats = stats;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Cout = w.cout;
+    a.tiles_x = ceil_div(W, 32); a.tiles_y = ceil_div(H, 4); a.tiles_z = ceil_div(D, 4);
+    const long tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * N;
+    MI355_REQUIRE(tiles < (1l << 30), "stem conv grid too large");
+    a.div_tiles_per_n = make_fastdiv(a.tiles_x * a.tiles_y * a.tiles_z);
+    a.div_tiles_x = make_fastdiv(a.tiles_x);
+    a.div_tiles_y = make_fastdiv(a.tiles_y);
+    a.act = act; a.slope = slope;
+    dim3 grid((unsigned)tiles, w.cout / 32);
+    if (w.dtype == MI355_F16) {
+        const size_t lds = (size_t)S_BRICK * 8 < 2048 ? 2048 : (size_t)S_BRICK * 8;
+        hipLaunchKernelGGL(conv3_stem_f16_kernel, grid, dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(conv3_stem_f32_kernel, grid, dim3(256), (size_t)S_BRICK * 16, s, a);
+    }
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+}  // namespace mi355

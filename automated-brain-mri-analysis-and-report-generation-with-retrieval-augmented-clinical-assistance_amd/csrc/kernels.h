@@ -44,6 +44,17 @@ struct ConvCall {
 int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name = nullptr);
 int conv3d_direct_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s);
 
+// first conv of the network (Cin <= 4): x-taps folded into K, NDHW4 input (conv_stem.hip)
+struct StemWeights {
+    int cin = 0, cout = 0, dtype = 0;
+    void *wp_dev = nullptr;
+    float *bias_dev = nullptr;
+};
+int stem_weights_upload(const float *w_host, const float *bias_host, int cin, int cout, int dtype, StemWeights *out);
+void stem_weights_free(StemWeights *w);
+int conv3d_stem(const StemWeights &w, const void *in, int N, int D, int H, int W, void *out, double *stats, int act,
+                float slope, hipStream_t s);
+
 // fp16 storage / fp32 accumulate variants (conv3d_f16.hip)
 struct ConvWeightsH {
     int cin = 0, cin_pad = 0, cout = 0, stride = 1, nf = 1;

@@ -32,6 +32,8 @@ void set_error(const char *fmt, ...) {
 struct ConvLayer {
     ConvWeights w;     // MI355_F32
     ConvWeightsH wh;   // MI355_F16
+    StemWeights stem;  // first conv of the net when Cin <= 4 (either dtype)
+    bool is_stem = false;
     float *gamma_dev = nullptr, *beta_dev = nullptr;  // Instance/GroupNorm affine, or BN scale/shift (nonlin_first)
     bool runtime_norm = false;                        // statistics needed at run time (IN / GN)
     bool post_affine = false;                         // BN that could not be folded (nonlin_first)
@@ -82,7 +84,7 @@ static int upload(const float *host, size_t n, float **dev) {
     return MI355_OK;
 }
 
-static int build_conv(const mi355_unet &net, const mi355_conv_desc &d, int cin_phys, ConvLayer *out) {
+static int build_conv(const mi355_unet &net, const mi355_conv_desc &d, int cin_phys, ConvLayer *out, bool stem = false) {
     MI355_REQUIRE(d.weight != nullptr, "conv %d->%d: null weight", d.cin, d.cout);
     MI355_REQUIRE(d.cin > 0 && d.cout > 0 && cin_phys >= d.cin, "conv: bad channel counts %d->%d (phys %d)", d.cin, d.cout, cin_phys);
     ConvLayer L;
@@ -121,7 +123,8 @@ static int build_conv(const mi355_unet &net, const mi355_conv_desc &d, int cin_p
         MI355_TRY(upload(g.data(), d.cout, &L.gamma_dev));
         MI355_TRY(upload(be.data(), d.cout, &L.beta_dev));
     }
-    if (net.dtype == MI355_F16) MI355_TRY(conv_weights_upload_f16(w.data(), b.data(), d.cin, cin_phys, d.cout, d.stride, &L.wh));
+    if (stem) { L.is_stem = true; MI355_TRY(stem_weights_upload(w.data(), b.data(), d.cin, d.cout, net.dtype, &L.stem)); }
+    else if (net.dtype == MI355_F16) MI355_TRY(conv_weights_upload_f16(w.data(), b.data(), d.cin, cin_phys, d.cout, d.stride, &L.wh));
     else MI355_TRY(conv_weights_upload(w.data(), b.data(), d.cin, cin_phys, d.cout, d.stride, false, &L.w));
     *out = L;
     return MI355_OK;
@@ -130,6 +133,7 @@ static int build_conv(const mi355_unet &net, const mi355_conv_desc &d, int cin_p
 static void free_conv(ConvLayer *L) {
     conv_weights_free(&L->w);
     conv_weights_free_f16(&L->wh);
+    stem_weights_free(&L->stem);
     if (L->gamma_dev) (void)hipFree(L->gamma_dev);
     if (L->beta_dev) (void)hipFree(L->beta_dev);
 }
@@ -245,7 +249,10 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
         const double es = f16 ? 2.0 : 4.0;
         const double flops = 2.0 * N * Vo * L.cout * (double)L.cin * 27.0;
         const double bytes = es * ((double)N * Di * Hi * Wi * (C0 + C1) + (double)N * Vo * L.cout + (double)L.cout * L.cin * 27.0);
-        if (f16) {
+        if (L.is_stem) {
+            ProfScope ps(net, s, f16 ? "conv3_stem_f16_kernel" : "conv3_stem_f32_kernel", flops, bytes);
+            MI355_TRY(conv3d_stem(L.stem, in0, N, Di, Hi, Wi, out, stats_arg, act, net->slope, s));
+        } else if (f16) {
             ConvCallH c;
             c.in0 = (const _Float16 *)in0; c.in1 = (const _Float16 *)in1; c.C0 = C0; c.C1 = C1;
             c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi; c.out = (_Float16 *)out; c.slope = net->slope;
@@ -523,6 +530,9 @@ extern "C" int mi355_unet_create(const mi355_unet_desc *d, mi355_unet_t *out) {
     MI355_REQUIRE(d->norm >= MI355_NORM_NONE && d->norm <= MI355_NORM_GROUP, "norm kind %d", d->norm);
     mi355_unet *net = new mi355_unet();
     net->in_channels = d->in_channels; net->cin_pad = d->dtype == MI355_F16 ? 16 : 8; net->num_classes = d->num_classes;
+    const bool use_stem = d->in_channels <= 4 && d->n_convs > 0 && d->convs[0].cout % 32 == 0 && d->convs[0].stride == 1 &&
+                          !(getenv("MI355_NO_STEM") && getenv("MI355_NO_STEM")[0] == '1');
+    if (use_stem) net->cin_pad = 4;  // NDHW4 input, x-taps folded into K (conv_stem.hip)
     net->num_pool = d->num_pool; net->norm = d->norm; net->num_groups = d->num_groups;
     net->nonlin_first = d->nonlin_first; net->dtype = d->dtype; net->eps = d->eps; net->slope = d->lrelu_slope;
     int rc = MI355_OK;
@@ -543,7 +553,7 @@ extern "C" int mi355_unet_create(const mi355_unet_desc *d, mi355_unet_t *out) {
             const int logical_in = (l == 0 && i == 0) ? d->in_channels : prevC;
             if (cd.cin != logical_in) { set_error("encoder conv %d.%d: cin %d, expected %d", l, i, cd.cin, logical_in); return fail(MI355_ERR_INVALID); }
             ConvLayer L;
-            rc = build_conv(*net, cd, prevC, &L);
+            rc = build_conv(*net, cd, prevC, &L, use_stem && l == 0 && i == 0);
             if (rc != MI355_OK) return fail(rc);
             net->enc[l].push_back(L);
             prevC = cd.cout;
@@ -719,6 +729,15 @@ extern "C" int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w
                                   const float *bias_host, int cout, int stride, int act, float slope, int impl, float *y_dev,
                                   void *stream) {
     MI355_TRY(require_device());
+    if (cin == 4 && stride == 1 && impl == 0 && cout % 32 == 0) {  // the network's first-layer kernel
+        StemWeights sw;
+        MI355_TRY(stem_weights_upload(weight_host, bias_host, cin, cout, MI355_F32, &sw));
+        int rc = conv3d_stem(sw, x_dev, n, d, h, w, y_dev, nullptr, act, slope, (hipStream_t)stream);
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        stem_weights_free(&sw);
+        if (rc == MI355_OK && e != hipSuccess) { set_error("stem conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
+        return rc;
+    }
     ConvWeights cw;
     MI355_TRY(conv_weights_upload(weight_host, bias_host, cin, cin, cout, stride, impl == 1, &cw));
     ConvCall c;
@@ -746,6 +765,15 @@ extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, in
                                       const float *bias_host, int cout, int stride, int act, float slope, void *y_dev,
                                       void *stream) {
     MI355_TRY(require_device());
+    if (cin == 4 && stride == 1 && cout % 32 == 0) {
+        StemWeights sw;
+        MI355_TRY(stem_weights_upload(weight_host, bias_host, cin, cout, MI355_F16, &sw));
+        int rc = conv3d_stem(sw, x_dev, n, d, h, w, y_dev, nullptr, act, slope, (hipStream_t)stream);
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        stem_weights_free(&sw);
+        if (rc == MI355_OK && e != hipSuccess) { set_error("stem conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
+        return rc;
+    }
     ConvWeightsH cw;
     MI355_TRY(conv_weights_upload_f16(weight_host, bias_host, cin, cin, cout, stride, &cw));
     ConvCallH c;

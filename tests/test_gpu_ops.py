@@ -29,6 +29,8 @@ CONV_CASES = [
     (1, 16, 16, 32, 32, 64, 2, 0),     # stride 2
     (2, 10, 6, 14, 64, 32, 2, 1),      # stride 2, ragged / odd output dims
     (1, 32, 32, 32, 64, 64, 1, 0),     # several chunks (4 x 16 channels), many tiles
+    (2, 8, 12, 40, 4, 32, 1, 1),       # the network's first layer: Cin = 4 -> stem kernel (x-taps folded into K), ragged
+    (1, 16, 16, 32, 4, 64, 1, 0),      # stem with two cout blocks
 ]
 
 
@@ -144,6 +146,8 @@ F16_CONV_CASES = [
     (2, 10, 6, 14, 64, 32, 2, 1),
     (1, 32, 32, 32, 64, 64, 1, 0),
     (8, 16, 16, 32, 32, 32, 1, 1),   # enough tiles for the 512-voxel (MF=4) pipelined variant
+    (2, 8, 12, 40, 4, 32, 1, 1),     # first layer, Cin = 4: stem kernel
+    (1, 16, 16, 32, 4, 64, 1, 0),
 ]
 
 
