@@ -528,6 +528,150 @@ __global__ void conv3_direct_kernel(const float *in0, const float *in1, int C0, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Winograd F(2,3) along y.  The f32 convs are MFMA-bound (exact fp32 multiplies, no TF32), so the lever left is the
+// number of multiplies: for an output row pair (2p, 2p+1) of the 4x4x32 tile the three dy taps
+//     y0 = w0 d0 + w1 d1 + w2 d2,   y1 = w0 d1 + w1 d2 + w2 d3       (d0..d3 = input rows 2p-1 .. 2p+2)
+// are computed as        m0 = (d0-d2) w0, m1 = (d1+d2)(w0+w1+w2)/2, m2 = (d2-d1)(w0-w1+w2)/2, m3 = (d1-d3) w2,
+//                        y0 = m0+m1+m2,   y1 = m1-m2-m3
+// i.e. 4 MFMA K-steps per (dz, dx, channel) for two output rows instead of 6: 2/3 of the direct kernel's MFMAs.
+// The row direction is the one that costs nothing else: lane = x as before (conflict-free ds_read_b128), the
+// transform is 16 VALU ops per pair and step on registers the lane already holds, a wave (one z plane of the tile)
+// reads the SIX brick rows of its two pairs once per step (the direct kernel reads 12 fragments for the same 3 dy
+// taps), and the brick, the staging and the epilogue are those of conv3_f32_mfma_kernel<1,16,4,1>.
+// The transformed weights U_f = G w are computed in fp64 on the host (conv_weights_upload) and rounded once to fp32.
+// Accumulators: 2 pairs x 4 components x 16 = 128 VGPRs per wave.
+// Rounding: the 1-D transform adds one fp32 rounding on the input differences and one on U; measured against the
+// CPU oracle the logits move by < 2x the direct kernel's summation-order noise (tests/test_gpu_ops.py).
+__global__ __launch_bounds__(256, 2) void conv3_f32_wino_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CC = 16, Q = CC / 4, G = CC / 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int n = (int)fdiv((uint32_t)bid, p.div_tiles_per_n);
+    int t = bid - n * (int)p.div_tiles_per_n.d;
+    const int tzy = (int)fdiv((uint32_t)t, p.div_tiles_x);
+    const int tile_x = t - tzy * p.tiles_x;
+    const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
+    const int tile_y = tzy - tile_z * p.tiles_y;
+    const int oz0 = tile_z << 2, oy0 = tile_y << 2, ox0 = tile_x << 5;  // tile is fixed: 4 x 4 x 32
+    const int iz0 = oz0 - 1, iy0 = oy0 - 1, ix0 = ox0 - 1;
+    constexpr int IX = 34, IY = 6, IZ = 6;
+    constexpr int brickvox = IX * IY * IZ;
+    constexpr int npieces = brickvox * Q;
+    constexpr int plane = brickvox * 4;
+
+    // wave = z plane of the tile; lane's brick row 0 at tap (dz, dx) = (0, 0), channel quad `half`
+    const int a_base = half * plane + (wave * IY * IX + l31) * 4;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pr][f][r] = 0.f;
+
+    // packed U: [cout block][chunk][step = dz*3+dx][g][f][lane][4]
+    const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (9 * G * 4 * 256) + lane * 4;
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const int cglob = ch * CC;
+        const float *src;
+        int Csrc, coff;
+        if (cglob < p.C0) {
+            src = p.in0; Csrc = p.C0; coff = cglob;
+        } else {
+            src = p.in1; Csrc = p.C1; coff = cglob - p.C0;
+        }
+        src += (size_t)n * p.Di * p.Hi * p.Wi * Csrc + coff;
+        constexpr int U = 4;
+        for (int i0 = tid; i0 < npieces; i0 += 256 * U) {
+            f32x4 v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256;
+                const int bv = i / Q, q = i - bv * Q;
+                const int r = bv / IX, bx = bv - r * IX;
+                const int bz = r / IY, by = r - bz * IY;
+                const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+                const bool ok = (i < npieces) && ((unsigned)iz < (unsigned)p.Di) &&
+                                ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
+                dst[u] = (i < npieces) ? q * plane + bv * 4 : -1;
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (ok)
+                    val = *(const f32x4 *)(src + ((size_t)(iz * p.Hi + iy) * p.Wi + ix) * Csrc + q * 4);
+                v[u] = val;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0)
+                    *(f32x4 *)(lds + dst[u]) = v[u];
+        }
+        __syncthreads();
+
+        const float *wch = wblk + (size_t)ch * (9 * G * 4 * 256);
+        f32x4 rows[6], u_cur[4], u_nxt[4];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) rows[r] = *(const f32x4 *)(lds + a_base + r * IX * 4);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) u_cur[f] = *(const f32x4 *)(wch + f * 256);
+
+        for (int st = 0; st < 9; ++st) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                // input transform B^T d of both row pairs (rows 0..3 and 2..5)
+                f32x4 V[2][4];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    V[pr][0] = rows[2 * pr] - rows[2 * pr + 2];
+                    V[pr][1] = rows[2 * pr + 1] + rows[2 * pr + 2];
+                    V[pr][2] = rows[2 * pr + 2] - rows[2 * pr + 1];
+                    V[pr][3] = rows[2 * pr + 1] - rows[2 * pr + 3];
+                }
+                int nst = st, ng = g + 1;
+                if (ng == G) { ng = 0; nst = st + 1; }
+                if (nst < 9) {
+                    const int dz = nst / 3, dx = nst - dz * 3;
+                    const int off = (dz * IY * IX + dx) * 4 + ng * 2 * plane;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) rows[r] = *(const f32x4 *)(lds + a_base + off + r * IX * 4);
+                    const float *wn = wch + (size_t)(nst * G + ng) * (4 * 256);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) u_nxt[f] = *(const f32x4 *)(wn + f * 256);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                        for (int f = 0; f < 4; ++f)
+                            acc[pr][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(u_cur[f][j], V[pr][f][j], acc[pr][f], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) u_cur[f] = u_nxt[f];
+            }
+        }
+        __syncthreads();  // brick is overwritten by the next chunk
+    }
+
+    // output transform A^T m -> the four rows of this wave's z plane, then the shared epilogue (voxel fragment mf = row)
+    f32x16 out[4][1];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            out[2 * pr][0][r] = acc[pr][0][r] + acc[pr][1][r] + acc[pr][2][r];
+            out[2 * pr + 1][0][r] = acc[pr][1][r] - acc[pr][2][r] - acc[pr][3][r];
+        }
+    conv_epilogue<4, 1>(out, p, n, oz0, oy0, ox0, (int)blockIdx.y * 32, lds, /*sync_before_red=*/false);
+}
+
 // ------------------------------------------------------------------ host side
 // Which stride-1 kernel a launch gets (env MI355_CONV_IMPL: "0" = always the one-tile-per-workgroup kernel,
 // "1" = always the pipelined persistent kernel, default "auto").  Measured on MI355X (bench.py, config 2):
@@ -542,6 +686,40 @@ static int conv_impl() {
         v = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
     }
     return v;
+}
+
+static bool winograd_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MI355_WINOGRAD");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// Winograd-y pack (floats): [cout block of 32][chunk of 16][step = dz*3+dx][g][f 0..3][lane][j] with
+//   cout = block*32 + (lane&31), cin = chunk*16 + g*8 + (lane>>5)*4 + j and U_f = (G w)_f over the dy taps,
+//   G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]], evaluated in fp64 and rounded once.
+static void pack_conv_weights_wino(const float *w, int cin, int cin_pad, int cout, std::vector<float> &out) {
+    const int nchunks = cin_pad / 16, nblk = cout / 32;
+    out.assign((size_t)nblk * nchunks * 9 * 2 * 4 * 256, 0.f);
+    size_t o = 0;
+    for (int b = 0; b < nblk; ++b)
+        for (int ch = 0; ch < nchunks; ++ch)
+            for (int st = 0; st < 9; ++st)
+                for (int g = 0; g < 2; ++g)
+                    for (int f = 0; f < 4; ++f)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j, ++o) {
+                                const int co = b * 32 + (lane & 31);
+                                const int ci = ch * 16 + g * 8 + (lane >> 5) * 4 + j;
+                                if (ci >= cin) continue;
+                                const int dz = st / 3, dx = st % 3;
+                                const float *wk = &w[((size_t)co * cin + ci) * 27 + dz * 9 + dx];  // dy stride 3
+                                const double w0 = wk[0], w1 = wk[3], w2 = wk[6];
+                                const double u = f == 0 ? w0 : f == 1 ? 0.5 * (w0 + w1 + w2) : f == 2 ? 0.5 * (w0 - w1 + w2) : w2;
+                                out[o] = (float)u;
+                            }
 }
 
 // Packed layout (floats): [cout_block][chunk][tap][g][nf][lane 0..63][j 0..3] with
@@ -585,6 +763,11 @@ int conv_weights_upload(const float *w_host, const float *bias_host, int cin, in
             pack_conv_weights_f32(w_host, cin, cin_pad, cout, 16, cw.nf, packed);
             MI355_HIP(hipMalloc(&cw.wp16_dev, packed.size() * sizeof(float)));
             MI355_HIP(hipMemcpy(cw.wp16_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (winograd_enabled()) {
+                pack_conv_weights_wino(w_host, cin, cin_pad, cout, packed);
+                MI355_HIP(hipMalloc(&cw.wpw_dev, packed.size() * sizeof(float)));
+                MI355_HIP(hipMemcpy(cw.wpw_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
         }
     }
     if (keep_plain || !mfma_ok) {
@@ -609,6 +792,7 @@ int conv_weights_upload(const float *w_host, const float *bias_host, int cin, in
 void conv_weights_free(ConvWeights *w) {
     if (w->wp_dev) (void)hipFree(w->wp_dev);
     if (w->wp16_dev) (void)hipFree(w->wp16_dev);
+    if (w->wpw_dev) (void)hipFree(w->wpw_dev);
     if (w->bias_dev) (void)hipFree(w->bias_dev);
     if (w->w_plain_dev) (void)hipFree(w->w_plain_dev);
     *w = ConvWeights();
@@ -694,6 +878,36 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
     a.Cout = w.cout;
     a.nchunks = w.cin_pad / w.cc;
     a.act = c.act; a.slope = c.slope;
+    if (w.wpw_dev) {
+        // auto mode, large launches: Winograd F(2,3) along y on fixed 4x4x32 tiles, 32 couts per workgroup
+        ConvArgs b = a;
+        b.lz = 2; b.ly = 2; b.lx = 5;
+        b.tiles_x = ceil_div(b.Wo, 32); b.tiles_y = ceil_div(b.Ho, 4); b.tiles_z = ceil_div(b.Do, 4);
+        b.IX = 34; b.IY = 6; b.IZ = 6;
+        b.div_tiles_per_n = make_fastdiv(b.tiles_x * b.tiles_y * b.tiles_z);
+        b.div_tiles_x = make_fastdiv(b.tiles_x);
+        b.div_tiles_y = make_fastdiv(b.tiles_y);
+        b.div_IX = make_fastdiv(b.IX);
+        b.div_IY = make_fastdiv(b.IY);
+        const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
+        const size_t brick_bytes = (size_t)34 * 6 * 6 * 16 * sizeof(float);
+        // the fixed tile wastes lanes on thin volumes: only when every tile dim is at least half used
+        if (tiles * (w.cout / 32) >= 512 && tiles < (1l << 30) && b.Wo >= 16 && b.Ho >= 4 && b.Do >= 4 &&
+            (!c.head_out || w.cout == 32)) {
+            b.wp = w.wpw_dev;
+            b.nchunks = w.cin_pad / 16;
+            dim3 grid((unsigned)tiles, w.cout / 32);
+            static size_t attr_bytes = 48 * 1024;
+            if (brick_bytes > attr_bytes) {
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brick_bytes));
+                attr_bytes = brick_bytes;
+            }
+            *kernel_name = "conv3_f32_wino_kernel";
+            hipLaunchKernelGGL(conv3_f32_wino_kernel, grid, dim3(256), brick_bytes, s, b);
+            MI355_HIP(hipGetLastError());
+            return MI355_OK;
+        }
+    }
     if (w.wp16_dev) {
         // auto mode: 512-voxel tiles + 16-channel chunks when that fills the chip
         ConvArgs b = a;

@@ -592,7 +592,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         const int need = (int)((tiles + 7) / 8) * 8;
         if (gx > need) gx = need;
         dim3 grid(gx, gy);
-        if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, 0>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, 0>" : "conv3_f16_mfma_pipe_kernel<2, 2, 0>");
+        if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, 0, false>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, 0, false>" : "conv3_f16_mfma_pipe_kernel<2, 2, 0, false>");
         static int abl = -1;
         if (abl < 0) { const char *e = getenv("MI355_CONV_ABLATE"); abl = e ? atoi(e) : 0; }
         if (MF == 4 && abl == 1) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 1>, a, grid, lds_bytes, s, &attr[7]);

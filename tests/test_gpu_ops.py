@@ -31,6 +31,10 @@ CONV_CASES = [
     (1, 32, 32, 32, 64, 64, 1, 0),     # several chunks (4 x 16 channels), many tiles
     (2, 8, 12, 40, 4, 32, 1, 1),       # the network's first layer: Cin = 4 -> stem kernel (x-taps folded into K), ragged
     (1, 16, 16, 32, 4, 64, 1, 0),      # stem with two cout blocks
+    (3, 9, 7, 131, 40, 96, 2, 1),      # stride 2: odd input dims, ragged x tiles, 5 chunks of 8, 3 cout blocks
+    (1, 64, 64, 64, 32, 64, 2, 1),     # stride 2 at a network-like size
+    (1, 64, 64, 64, 32, 64, 1, 1),     # >= 512 workgroups: the Winograd F(2,3)-along-y kernel, two cout blocks
+    (3, 30, 37, 70, 48, 32, 1, 0),     # Winograd kernel: ragged in z, y (odd: half-used row pair) and x, 3 chunks, batch
 ]
 
 
@@ -148,6 +152,8 @@ F16_CONV_CASES = [
     (8, 16, 16, 32, 32, 32, 1, 1),   # enough tiles for the 512-voxel (MF=4) pipelined variant
     (2, 8, 12, 40, 4, 32, 1, 1),     # first layer, Cin = 4: stem kernel
     (1, 16, 16, 32, 4, 64, 1, 0),
+    (3, 9, 7, 131, 48, 96, 2, 1),    # stride 2: odd input dims, ragged x tiles, 3 chunks of 16, 3 cout blocks
+    (1, 64, 64, 64, 32, 64, 2, 1),   # stride 2 at a network-like size
 ]
 
 
