@@ -688,13 +688,243 @@ static int conv_impl() {
     return v;
 }
 
-static bool winograd_enabled() {
+// ---------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) over (z, y): the nested form of the kernel above.  A wave owns one 2x2 (z, y) output block of
+// the 4x4x32 tile at 32 x positions; per (dx, channel) it reads the block's 4x4 input rows, transforms them to 16
+// components V = B^T D B (32 packed adds on 2-channel pairs) and issues 16 MFMA K-steps - 4 per output row instead
+// of 9 (direct) or 6 (F(2,3) along y only).  The 16 component accumulators are 256 registers, so the kernel runs ONE
+// wave per SIMD (512-register budget, accumulators in AGPRs), one persistent workgroup per CU, and everything that a
+// second workgroup used to hide is overlapped inside the wave:
+//   * a step is (channel quad, dx): one 8-B LDS read per row (lane half h holds channels 2h, 2h+1 of the quad), two
+//     MFMAs per component; rows and weights of step s+1 are fetched while the 32 MFMAs of step s run;
+//   * the 16-channel halo brick is double-buffered (2 x 77 KB of the 160 KB LDS) and filled by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers, no ds_write): a wave-instruction writes 64 consecutive 16-B
+//     slots of one quad plane, out-of-volume voxels read a zero page; the 4 quads of a 64-voxel range are issued
+//     back to back so the 128-B lines they share are still in the vector L1.  The chunk-end __syncthreads retires
+//     the DMA (vmcnt(0)) before the barrier, which is the ordering a ds_read of DMA data needs.
+struct Wino2Args {
+    ConvArgs c;
+    int total_tiles;
+    const float *zeros;  // >= 16 B of zeros in global memory: the source of every out-of-volume piece
+};
+
+constexpr int W2_IX = 34, W2_IY = 6, W2_IZ = 6, W2_BV = W2_IX * W2_IY * W2_IZ;  // 1224 brick voxels
+constexpr int W2_BUF_FLOATS = (4 * W2_BV + 56) * 4;  // 4 quad planes + the overrun of the last DMA range
+constexpr size_t W2_LDS_BYTES = (size_t)(2 * W2_BUF_FLOATS + 4 * 32 * 2) * sizeof(float);
+
+__global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const ConvArgs &p = pa.c;
+    constexpr int IX = W2_IX, IY = W2_IY, BV = W2_BV;
+    constexpr int plane = BV * 4;  // floats per channel-quad plane
+    constexpr int STEPS = 12;      // (quad 0..3) x (dx 0..2) per 16-channel chunk
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int bz = wave >> 1, by = wave & 1;
+    float *red = lds + 2 * W2_BUF_FLOATS;
+
+    // this workgroup's tile sequence: XCD group x owns the contiguous range [lo, hi); its workgroups stride through it
+    const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x - xcd + 7) >> 3;
+    const int q8 = pa.total_tiles >> 3, r8 = pa.total_tiles & 7;
+    const int lo = xcd * q8 + (xcd < r8 ? xcd : r8);
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + li;
+    if (tile >= hi) return;
+
+    struct TileCoord { int n, oz0, oy0, ox0; };
+    auto decode = [&](int t) {
+        TileCoord tc;
+        tc.n = (int)fdiv((uint32_t)t, p.div_tiles_per_n);
+        const int tt = t - tc.n * (int)p.div_tiles_per_n.d;
+        const int tzy = (int)fdiv((uint32_t)tt, p.div_tiles_x);
+        const int tile_x = tt - tzy * p.tiles_x;
+        const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
+        const int tile_y = tzy - tile_z * p.tiles_y;
+        tc.oz0 = tile_z << 2; tc.oy0 = tile_y << 2; tc.ox0 = tile_x << 5;
+        return tc;
+    };
+    // LDS-DMA of slots [q*BV + 64*rng, +64) of `buf`: slot i holds channel quad i / BV of brick voxel i % BV (the tail
+    // of range 19 runs into the next plane with exactly the data that belongs there; past the last plane into padding)
+    // (the four quads of one 64-voxel range; the lane's voxel decode is recomputed at every call on purpose: hoisted out
+    //  of the tile loop it costs 60 VGPRs that do not exist here)
+    auto stage_dma4 = [&](const TileCoord &tc, int ch, int rng, float *buf) {
+        const int cglob = ch * 16;
+        const float *src; int Csrc, coff;
+        if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
+        else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
+        src += (size_t)tc.n * p.Di * p.Hi * p.Wi * Csrc + coff;  // wave-uniform; the per-lane part fits 32 bits (host check)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        int bv = rng * 64 + ln;
+        const int over = bv >= BV ? 1 : 0;  // tail of range 19: slots of the NEXT quad plane, voxels 0..55
+        bv -= over * BV;
+        const int rr = bv / IX, bx = bv - rr * IX;
+        const int rz = rr / IY, ry = rr - rz * IY;
+        const int iz = tc.oz0 - 1 + rz, iy = tc.oy0 - 1 + ry, ix = tc.ox0 - 1 + bx;
+        const bool in_vol = ((unsigned)iz < (unsigned)p.Di) && ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
+        const unsigned voff = (unsigned)(((iz * p.Hi + iy) * p.Wi + ix) * Csrc + over * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool inside = in_vol && (q + over < 4);
+            const float *g = inside ? src + voff + q * 4 : pa.zeros;
+            asm volatile("" : "+v"(g));  // one DMA per quad for every lane (a branchy select would issue two and break the vmcnt count)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(buf + (q * BV + rng * 64) * 4), 16, 0, 0);
+        }
+    };
+
+    // floats: block row (0,0) at dx = 0, quad 0, this lane's channel pair
+    const int a_base = ((2 * bz * IY + 2 * by) * IX + l31) * 4 + half * 2;
+
+    // packed U: [cout block][chunk][step = q*3 + dx][f 0..15][lane][2].  The weight fragments are fetched by inline-asm
+    // loads with hand-counted waits: while an LDS-DMA is in flight hipcc retires EVERY vector-memory operation
+    // (vmcnt(0)) before the first use of an ordinary load's result, which would make each step wait for the brick DMA
+    // issued one step earlier (HBM latency > one 2048-cycle step).  Ring u[2][16], indexed by step parity (no copies:
+    // a register must not be read before its wait).
+    const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (STEPS * 16 * 128);
+    const unsigned wl0 = lane * 8, wl1 = lane * 8 + 4096;  // byte offsets of this lane in fragments 0..7 / 8..15
+#define W2_ULOAD8(U, K, VOFF, SBASE)                                                                                              \
+    asm volatile("global_load_dwordx2 %0, %8, %9\n\tglobal_load_dwordx2 %1, %8, %9 offset:512\n\t"                                \
+                 "global_load_dwordx2 %2, %8, %9 offset:1024\n\tglobal_load_dwordx2 %3, %8, %9 offset:1536\n\t"                   \
+                 "global_load_dwordx2 %4, %8, %9 offset:2048\n\tglobal_load_dwordx2 %5, %8, %9 offset:2560\n\t"                   \
+                 "global_load_dwordx2 %6, %8, %9 offset:3072\n\tglobal_load_dwordx2 %7, %8, %9 offset:3584"                        \
+                 : "=v"(U[K + 0]), "=v"(U[K + 1]), "=v"(U[K + 2]), "=v"(U[K + 3]), "=v"(U[K + 4]), "=v"(U[K + 5]),                \
+                   "=v"(U[K + 6]), "=v"(U[K + 7])                                                                                  \
+                 : "v"(VOFF), "s"(SBASE)                                                                                           \
+                 : "memory")
+#define W2_UWAIT(U, N)                                                                                                            \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                        \
+                 : "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]), "+v"(U[4]), "+v"(U[5]), "+v"(U[6]), "+v"(U[7]), "+v"(U[8]),    \
+                   "+v"(U[9]), "+v"(U[10]), "+v"(U[11]), "+v"(U[12]), "+v"(U[13]), "+v"(U[14]), "+v"(U[15])                       \
+                 :                                                                                                                \
+                 : "memory")
+
+    TileCoord cur = decode(tile);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) stage_dma4(cur, 0, wave + 4 * k, lds);
+    f32x2 u[2][16];
+    W2_ULOAD8(u[0], 0, wl0, wblk);
+    W2_ULOAD8(u[0], 8, wl1, wblk);
+    __syncthreads();
+
+    int buf = 0;
+    // tile loop outside, chunk loop inside, accumulators scoped to one tile: a conditional reset inside a single
+    // flattened loop makes the register allocator spill the 256 accumulators at every back edge
+    for (; tile < hi; tile += nl) {
+        f32x16 acc[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+        const int ntile = tile + nl;
+        const TileCoord nxt_tile = ntile < hi ? decode(ntile) : cur;
+
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const bool last_ch = ch == p.nchunks - 1;
+            const bool have_next = !last_ch || ntile < hi;
+            const TileCoord nxt = last_ch ? nxt_tile : cur;
+            const int nch_eff = have_next ? (last_ch ? 0 : ch + 1) : ch;  // very last chunk: harmless weight re-read
+            const float *bufc = lds + buf * W2_BUF_FLOATS;
+            float *bufn = lds + (buf ^ 1) * W2_BUF_FLOATS;
+            const float *wch = wblk + (size_t)ch * (STEPS * 16 * 128);
+            const float *wnx = wblk + (size_t)nch_eff * (STEPS * 16 * 128);
+
+            f32x2 d[16];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) d[a * 4 + b] = *(const f32x2 *)(bufc + a_base + (a * IY + b) * IX * 4);
+
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                // V = B^T D B: first along y (index b) within each z row a, then along z
+                f32x2 T[16], V[16];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    T[a * 4 + 0] = d[a * 4 + 0] - d[a * 4 + 2];
+                    T[a * 4 + 1] = d[a * 4 + 1] + d[a * 4 + 2];
+                    T[a * 4 + 2] = d[a * 4 + 2] - d[a * 4 + 1];
+                    T[a * 4 + 3] = d[a * 4 + 1] - d[a * 4 + 3];
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    V[0 * 4 + b] = T[0 * 4 + b] - T[2 * 4 + b];
+                    V[1 * 4 + b] = T[1 * 4 + b] + T[2 * 4 + b];
+                    V[2 * 4 + b] = T[2 * 4 + b] - T[1 * 4 + b];
+                    V[3 * 4 + b] = T[1 * 4 + b] - T[3 * 4 + b];
+                }
+                if (st + 1 < STEPS) {
+                    const int nq = (st + 1) / 3, ndx = (st + 1) - nq * 3;
+                    const int off = nq * plane + ndx * 4;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) d[a * 4 + b] = *(const f32x2 *)(bufc + a_base + off + (a * IY + b) * IX * 4);
+                }
+                // this step's weights: everything older than the brick DMAs of the previous step must have landed
+                // (those 4 DMAs were issued after the weight loads and may stay in flight: they get two steps)
+                if (st > 0 && ((st - 1) & 1) == 0 && st - 1 < 10) W2_UWAIT(u[st & 1], 4);
+                else W2_UWAIT(u[st & 1], 0);
+                {
+                    const float *wn = (st + 1 < STEPS) ? wch + (size_t)(st + 1) * (16 * 128) : wnx;
+                    W2_ULOAD8(u[(st + 1) & 1], 0, wl0, wn);
+                    W2_ULOAD8(u[(st + 1) & 1], 8, wl1, wn);
+                }
+                // (without a next chunk the DMAs re-stage the current one into the idle buffer: the wait counts stay fixed)
+                if ((st & 1) == 0 && st < 10) stage_dma4(nxt, nch_eff, wave + 4 * (st >> 1), bufn);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int f = 0; f < 16; ++f)
+                        acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[st & 1][f][j], V[f][j], acc[f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);  // keep step s+2's fetches out of step s: the 256 arch VGPRs are the limit
+            }
+            __syncthreads();  // retires this chunk's DMA (vmcnt(0)) and orders it before the next chunk's ds_reads
+            buf ^= 1;
+        }
+        W2_UWAIT(u[0], 0);  // the next tile's first fragments are in flight: settle them before the epilogue may spill them
+
+        // Y = A^T M A: along y within each z component, then along z; rows ordered mf = 2*zrow + yrow
+        f32x16 out[4][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float P[4][2];
+#pragma unroll
+            for (int fz = 0; fz < 4; ++fz) {
+                P[fz][0] = acc[fz * 4 + 0][r] + acc[fz * 4 + 1][r] + acc[fz * 4 + 2][r];
+                P[fz][1] = acc[fz * 4 + 1][r] - acc[fz * 4 + 2][r] - acc[fz * 4 + 3][r];
+            }
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                out[0 + yy][0][r] = P[0][yy] + P[1][yy] + P[2][yy];
+                out[2 + yy][0][r] = P[1][yy] - P[2][yy] - P[3][yy];
+            }
+        }
+        // shared epilogue with a 2-row y tile: it places fragment mf of wave w at z = 2w + (mf>>1), y = mf&1, so
+        // shift the origin to this wave's block (z = 2bz + (mf>>1), y = 2by + (mf&1))
+        ConvArgs q = p;
+        q.lx = 5; q.ly = 1;
+        conv_epilogue<4, 1>(out, q, cur.n, cur.oz0 + 2 * bz - 2 * wave, cur.oy0 + 2 * by, cur.ox0, (int)blockIdx.y * 32, red,
+                            /*sync_before_red=*/false);
+        cur = nxt_tile;
+    }
+#undef W2_ULOAD8
+#undef W2_UWAIT
+}
+
+// MI355_WINOGRAD: 0 = direct kernels only, 1 = F(2,3) along y, 2 (default) = F(2x2,3x3) over (z, y)
+static int winograd_mode() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("MI355_WINOGRAD");
-        v = (e && e[0] == '0') ? 0 : 1;
+        v = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
     }
-    return v == 1;
+    return v;
 }
 
 // Winograd-y pack (floats): [cout block of 32][chunk of 16][step = dz*3+dx][g][f 0..3][lane][j] with
@@ -720,6 +950,32 @@ static void pack_conv_weights_wino(const float *w, int cin, int cin_pad, int cou
                                 const double u = f == 0 ? w0 : f == 1 ? 0.5 * (w0 + w1 + w2) : f == 2 ? 0.5 * (w0 - w1 + w2) : w2;
                                 out[o] = (float)u;
                             }
+}
+
+// 2-D Winograd pack (floats): [cout block of 32][chunk of 16][step = q*3+dx][f = fz*4+fy][lane][j 0..1] with
+//   cout = block*32 + (lane&31), cin = chunk*16 + q*4 + (lane>>5)*2 + j, U = G w G^T over the (dz, dy) taps.
+static void pack_conv_weights_wino2(const float *w, int cin, int cin_pad, int cout, std::vector<float> &out) {
+    const int nchunks = cin_pad / 16, nblk = cout / 32;
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    out.assign((size_t)nblk * nchunks * 12 * 16 * 128, 0.f);
+    size_t o = 0;
+    for (int b = 0; b < nblk; ++b)
+        for (int ch = 0; ch < nchunks; ++ch)
+            for (int st = 0; st < 12; ++st)
+                for (int f = 0; f < 16; ++f)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 2; ++j, ++o) {
+                            const int co = b * 32 + (lane & 31);
+                            const int q = st / 3, dx = st % 3;
+                            const int ci = ch * 16 + q * 4 + (lane >> 5) * 2 + j;
+                            if (ci >= cin) continue;
+                            const float *wk = &w[((size_t)co * cin + ci) * 27 + dx];  // [dz][dy] at strides 9, 3
+                            const int fz = f >> 2, fy = f & 3;
+                            double u = 0.0;
+                            for (int dz = 0; dz < 3; ++dz)
+                                for (int dy = 0; dy < 3; ++dy) u += Gm[fz][dz] * Gm[fy][dy] * (double)wk[dz * 9 + dy * 3];
+                            out[o] = (float)u;
+                        }
 }
 
 // Packed layout (floats): [cout_block][chunk][tap][g][nf][lane 0..63][j 0..3] with
@@ -763,8 +1019,10 @@ int conv_weights_upload(const float *w_host, const float *bias_host, int cin, in
             pack_conv_weights_f32(w_host, cin, cin_pad, cout, 16, cw.nf, packed);
             MI355_HIP(hipMalloc(&cw.wp16_dev, packed.size() * sizeof(float)));
             MI355_HIP(hipMemcpy(cw.wp16_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-            if (winograd_enabled()) {
-                pack_conv_weights_wino(w_host, cin, cin_pad, cout, packed);
+            if (winograd_mode() != 0) {
+                cw.wino2 = winograd_mode() == 2;
+                if (cw.wino2) pack_conv_weights_wino2(w_host, cin, cin_pad, cout, packed);
+                else pack_conv_weights_wino(w_host, cin, cin_pad, cout, packed);
                 MI355_HIP(hipMalloc(&cw.wpw_dev, packed.size() * sizeof(float)));
                 MI355_HIP(hipMemcpy(cw.wpw_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
             }
@@ -893,17 +1151,31 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
         const size_t brick_bytes = (size_t)34 * 6 * 6 * 16 * sizeof(float);
         // the fixed tile wastes lanes on thin volumes: only when every tile dim is at least half used
         if (tiles * (w.cout / 32) >= 512 && tiles < (1l << 30) && b.Wo >= 16 && b.Ho >= 4 && b.Do >= 4 &&
+            (long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) < (1l << 31) &&
             (!c.head_out || w.cout == 32)) {
             b.wp = w.wpw_dev;
             b.nchunks = w.cin_pad / 16;
             dim3 grid((unsigned)tiles, w.cout / 32);
-            static size_t attr_bytes = 48 * 1024;
-            if (brick_bytes > attr_bytes) {
+            static float *zeros = nullptr;
+            if (!zeros) {
                 MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brick_bytes));
-                attr_bytes = brick_bytes;
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES));
+                MI355_HIP(hipMalloc(&zeros, 256));
+                MI355_HIP(hipMemset(zeros, 0, 256));
             }
-            *kernel_name = "conv3_f32_wino_kernel";
-            hipLaunchKernelGGL(conv3_f32_wino_kernel, grid, dim3(256), brick_bytes, s, b);
+            *kernel_name = w.wino2 ? "conv3_f32_wino2_kernel" : "conv3_f32_wino_kernel";
+            if (w.wino2) {
+                Wino2Args wa;
+                wa.c = b; wa.total_tiles = (int)tiles; wa.zeros = zeros;
+                const int gy = w.cout / 32;
+                int gx = 256 / gy;                      // one persistent workgroup per CU
+                gx = gx < 8 ? 8 : (gx / 8) * 8;         // multiple of 8: blockIdx.x & 7 labels the XCD group
+                const int need = (int)((tiles + 7) / 8) * 8;
+                if (gx > need) gx = need;
+                hipLaunchKernelGGL(conv3_f32_wino2_kernel, dim3(gx, gy), dim3(256), W2_LDS_BYTES, s, wa);
+            } else {
+                hipLaunchKernelGGL(conv3_f32_wino_kernel, grid, dim3(256), brick_bytes, s, b);
+            }
             MI355_HIP(hipGetLastError());
             return MI355_OK;
         }

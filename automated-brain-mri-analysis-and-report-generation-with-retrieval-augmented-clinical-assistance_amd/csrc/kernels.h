@@ -17,7 +17,8 @@ struct ConvWeights {
     bool pipe = false;        // pipelined (persistent, double-buffered) kernel; implies cc == 8
     float *wp_dev = nullptr;  // packed weights (device), chunk size cc
     float *wp16_dev = nullptr;  // second pack with 16-channel chunks for the 512-voxel-tile simple kernel (auto mode)
-    float *wpw_dev = nullptr;   // Winograd F(2,3)-along-y pack (stride 1, 16-channel chunks, 32-cout blocks)
+    float *wpw_dev = nullptr;   // Winograd pack (stride 1, 16-channel chunks, 32-cout blocks): F(2,3) along y, or
+    bool wino2 = false;         // F(2x2,3x3) over (z, y) when wino2
     float *bias_dev = nullptr;
     float *w_plain_dev = nullptr;  // [cout][cin][27] PyTorch order (direct kernel / tests)
     size_t wp_bytes = 0;
