@@ -749,68 +749,90 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
         return tc;
     };
     // LDS-DMA of slots [q*BV + 64*rng, +64) of `buf`: slot i holds channel quad i / BV of brick voxel i % BV (the tail
-    // of range 19 runs into the next plane with exactly the data that belongs there; past the last plane into padding)
-    // (the four quads of one 64-voxel range; the lane's voxel decode is recomputed at every call on purpose: hoisted out
-    //  of the tile loop it costs 60 VGPRs that do not exist here)
-    auto stage_dma4 = [&](const TileCoord &tc, int ch, int rng, float *buf) {
+    // of range 19 runs into the next plane with exactly the data that belongs there; past the last plane into padding).
+    // dma_decode: this lane's voxel of a 64-voxel range (recomputed at every call on purpose: hoisted out of the tile
+    // loop the decode costs 60 VGPRs that do not exist here); dma_issue: one quad of that range.
+    struct DmaLane { const float *src; unsigned voff; int over; bool in_vol; };
+    auto dma_decode = [&](const TileCoord &tc, int ch, int rng) {
+        DmaLane dl;
         const int cglob = ch * 16;
         const float *src; int Csrc, coff;
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
-        src += (size_t)tc.n * p.Di * p.Hi * p.Wi * Csrc + coff;  // wave-uniform; the per-lane part fits 32 bits (host check)
+        dl.src = src + (size_t)tc.n * p.Di * p.Hi * p.Wi * Csrc + coff;  // wave-uniform; the per-lane part fits 32 bits (host check)
         int ln = lane;
         asm volatile("" : "+v"(ln));
         int bv = rng * 64 + ln;
-        const int over = bv >= BV ? 1 : 0;  // tail of range 19: slots of the NEXT quad plane, voxels 0..55
-        bv -= over * BV;
+        dl.over = bv >= BV ? 1 : 0;  // tail of range 19: slots of the NEXT quad plane, voxels 0..55
+        bv -= dl.over * BV;
         const int rr = bv / IX, bx = bv - rr * IX;
         const int rz = rr / IY, ry = rr - rz * IY;
         const int iz = tc.oz0 - 1 + rz, iy = tc.oy0 - 1 + ry, ix = tc.ox0 - 1 + bx;
-        const bool in_vol = ((unsigned)iz < (unsigned)p.Di) && ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
-        const unsigned voff = (unsigned)(((iz * p.Hi + iy) * p.Wi + ix) * Csrc + over * 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool inside = in_vol && (q + over < 4);
-            const float *g = inside ? src + voff + q * 4 : pa.zeros;
-            asm volatile("" : "+v"(g));  // one DMA per quad for every lane (a branchy select would issue two and break the vmcnt count)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                             (__attribute__((address_space(3))) void *)(buf + (q * BV + rng * 64) * 4), 16, 0, 0);
-        }
+        dl.in_vol = ((unsigned)iz < (unsigned)p.Di) && ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
+        dl.voff = (unsigned)(((iz * p.Hi + iy) * p.Wi + ix) * Csrc + dl.over * 4);
+        return dl;
+    };
+    auto dma_issue = [&](const DmaLane &dl, int rng, int q, float *buf) {
+        const bool inside = dl.in_vol && (q + dl.over < 4);
+        const float *g = inside ? dl.src + dl.voff + q * 4 : pa.zeros;
+        asm volatile("" : "+v"(g));  // one DMA per quad for every lane (a branchy select would issue two and break the vmcnt count)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(buf + (q * BV + rng * 64) * 4), 16, 0, 0);
     };
 
     // floats: block row (0,0) at dx = 0, quad 0, this lane's channel pair
     const int a_base = ((2 * bz * IY + 2 * by) * IX + l31) * 4 + half * 2;
 
-    // packed U: [cout block][chunk][step = q*3 + dx][f 0..15][lane][2].  The weight fragments are fetched by inline-asm
-    // loads with hand-counted waits: while an LDS-DMA is in flight hipcc retires EVERY vector-memory operation
-    // (vmcnt(0)) before the first use of an ordinary load's result, which would make each step wait for the brick DMA
-    // issued one step earlier (HBM latency > one 2048-cycle step).  Ring u[2][16], indexed by step parity (no copies:
-    // a register must not be read before its wait).
+    // packed U: [cout block][chunk][step = q*3 + dx][fragment pair 0..7][lane][f&1][2] - one 16-B load per lane fetches
+    // the fragments 2k, 2k+1.  The loads are inline asm with hand-counted waits: while an LDS-DMA is in flight hipcc
+    // retires EVERY vector-memory operation (vmcnt(0)) before the first use of an ordinary load's result, which would
+    // make each step wait for the brick DMA issued just before (HBM latency > one 2048-cycle step).  Ring uq[2][8],
+    // indexed by step parity (no copies: a register must not be read before its wait).
     const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (STEPS * 16 * 128);
-    const unsigned wl0 = lane * 8, wl1 = lane * 8 + 4096;  // byte offsets of this lane in fragments 0..7 / 8..15
-#define W2_ULOAD8(U, K, VOFF, SBASE)                                                                                              \
-    asm volatile("global_load_dwordx2 %0, %8, %9\n\tglobal_load_dwordx2 %1, %8, %9 offset:512\n\t"                                \
-                 "global_load_dwordx2 %2, %8, %9 offset:1024\n\tglobal_load_dwordx2 %3, %8, %9 offset:1536\n\t"                   \
-                 "global_load_dwordx2 %4, %8, %9 offset:2048\n\tglobal_load_dwordx2 %5, %8, %9 offset:2560\n\t"                   \
-                 "global_load_dwordx2 %6, %8, %9 offset:3072\n\tglobal_load_dwordx2 %7, %8, %9 offset:3584"                        \
-                 : "=v"(U[K + 0]), "=v"(U[K + 1]), "=v"(U[K + 2]), "=v"(U[K + 3]), "=v"(U[K + 4]), "=v"(U[K + 5]),                \
-                   "=v"(U[K + 6]), "=v"(U[K + 7])                                                                                  \
-                 : "v"(VOFF), "s"(SBASE)                                                                                           \
-                 : "memory")
-#define W2_UWAIT(U, N)                                                                                                            \
-    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                        \
-                 : "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]), "+v"(U[4]), "+v"(U[5]), "+v"(U[6]), "+v"(U[7]), "+v"(U[8]),    \
-                   "+v"(U[9]), "+v"(U[10]), "+v"(U[11]), "+v"(U[12]), "+v"(U[13]), "+v"(U[14]), "+v"(U[15])                       \
-                 :                                                                                                                \
+    const unsigned wl0 = lane * 16, wl1 = lane * 16 + 4096;  // byte offsets of this lane in pairs 0..3 / 4..7
+#define W2_ULOAD(DST, VOFF, SBASE, IMM) \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(DST) : "v"(VOFF), "s"(SBASE), "n"(IMM) : "memory")
+#define W2_UWAIT(U, N)                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                             \
+                 : "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]), "+v"(U[4]), "+v"(U[5]), "+v"(U[6]), "+v"(U[7])      \
+                 :                                                                                                     \
                  : "memory")
 
     TileCoord cur = decode(tile);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) stage_dma4(cur, 0, wave + 4 * k, lds);
-    f32x2 u[2][16];
-    W2_ULOAD8(u[0], 0, wl0, wblk);
-    W2_ULOAD8(u[0], 8, wl1, wblk);
+    for (int k = 0; k < 5; ++k) {
+        const DmaLane dl = dma_decode(cur, 0, wave + 4 * k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma_issue(dl, wave + 4 * k, q, lds);
+    }
+    f32x4 uq[2][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < 4) W2_ULOAD(uq[0][k], wl0, wblk, (k & 3) * 1024);
+        else W2_ULOAD(uq[0][k], wl1, wblk, (k & 3) * 1024);
+    }
     __syncthreads();
+
+    // rows of step `st` (16 x ds_read_b64) / the two halves of the transform V = B^T D B (first along y within each z
+    // row a, then along z), one packed add per call so that they can be dealt out between the MFMAs
+    auto row_read = [&](const float *bufc, int st, int k) {
+        const int q = st / 3, dx = st - q * 3;
+        return *(const f32x2 *)(bufc + a_base + q * plane + dx * 4 + ((k >> 2) * IY + (k & 3)) * IX * 4);
+    };
+    // (packed adds spelled out: left to itself the compiler splits most of them into two v_add_f32, and every VALU
+    //  instruction between two MFMAs costs the matrix pipe its issue cycles)
+    auto pk_add = [](f32x2 x, f32x2 y) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    auto pk_sub = [](f32x2 x, f32x2 y) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    auto t_op = [&](const f32x2 (&d)[16], f32x2 (&T)[16], int i) {
+        const int a = i >> 2, k = i & 3;
+        T[i] = k == 0 ? pk_sub(d[a * 4 + 0], d[a * 4 + 2]) : k == 1 ? pk_add(d[a * 4 + 1], d[a * 4 + 2])
+             : k == 2 ? pk_sub(d[a * 4 + 2], d[a * 4 + 1]) : pk_sub(d[a * 4 + 1], d[a * 4 + 3]);
+    };
+    auto v_op = [&](const f32x2 (&T)[16], f32x2 (&V)[16], int m) {
+        const int fz = m >> 2, b = m & 3;
+        V[m] = fz == 0 ? pk_sub(T[0 * 4 + b], T[2 * 4 + b]) : fz == 1 ? pk_add(T[1 * 4 + b], T[2 * 4 + b])
+             : fz == 2 ? pk_sub(T[2 * 4 + b], T[1 * 4 + b]) : pk_sub(T[1 * 4 + b], T[3 * 4 + b]);
+    };
 
     int buf = 0;
     // tile loop outside, chunk loop inside, accumulators scoped to one tile: a conditional reset inside a single
@@ -828,66 +850,66 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
             const bool last_ch = ch == p.nchunks - 1;
             const bool have_next = !last_ch || ntile < hi;
             const TileCoord nxt = last_ch ? nxt_tile : cur;
-            const int nch_eff = have_next ? (last_ch ? 0 : ch + 1) : ch;  // very last chunk: harmless weight re-read
+            // (without a next chunk the DMAs re-stage the current one into the idle buffer: the wait counts stay fixed)
+            const int nch_eff = have_next ? (last_ch ? 0 : ch + 1) : ch;
             const float *bufc = lds + buf * W2_BUF_FLOATS;
             float *bufn = lds + (buf ^ 1) * W2_BUF_FLOATS;
             const float *wch = wblk + (size_t)ch * (STEPS * 16 * 128);
             const float *wnx = wblk + (size_t)nch_eff * (STEPS * 16 * 128);
 
-            f32x2 d[16];
+            // chunk prologue (exposed once per chunk): V of step 0, rows of step 1
+            f32x2 d[16], T[16], V[2][16];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int k = 0; k < 16; ++k) d[k] = row_read(bufc, 0, k);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) d[a * 4 + b] = *(const f32x2 *)(bufc + a_base + (a * IY + b) * IX * 4);
+            for (int i = 0; i < 16; ++i) t_op(d, T, i);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v_op(T, V[0], m);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d[k] = row_read(bufc, 1, k);
+            __builtin_amdgcn_sched_barrier(0);
 
+            // One step = 32 MFMAs (64 cycles each); everything else of the pipeline is dealt out between them, one
+            // scheduling fence per MFMA: the transform of step st+1 (its rows were read during step st-1), the weight
+            // loads of step st+1, the row reads of step st+2 and, on even steps, 4 brick DMAs of the next chunk.
+            DmaLane dl;
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
-                // V = B^T D B: first along y (index b) within each z row a, then along z
-                f32x2 T[16], V[16];
+                const int pp = st & 1;
+                // this step's weights: everything older than the 4 brick DMAs of the previous step must have landed
+                // (the DMAs were issued after the weight loads and may stay in flight: they get a step and a half)
+                if (st > 0 && ((st - 1) & 1) == 0 && st - 1 < 10) W2_UWAIT(uq[pp], 4);
+                else W2_UWAIT(uq[pp], 0);
+                const float *wn = (st + 1 < STEPS) ? wch + (size_t)(st + 1) * (16 * 128) : wnx;
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    T[a * 4 + 0] = d[a * 4 + 0] - d[a * 4 + 2];
-                    T[a * 4 + 1] = d[a * 4 + 1] + d[a * 4 + 2];
-                    T[a * 4 + 2] = d[a * 4 + 2] - d[a * 4 + 1];
-                    T[a * 4 + 3] = d[a * 4 + 1] - d[a * 4 + 3];
+                for (int i = 0; i < 32; ++i) {
+                    const int f = i & 15, j = i >> 4;
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(uq[pp][f >> 1][(f & 1) * 2 + j], V[pp][f][j], acc[f], 0, 0, 0);
+                    if (st + 1 < STEPS) {
+                        if (i < 8) { t_op(d, T, 2 * i); t_op(d, T, 2 * i + 1); }
+                        else if (i >= 16) v_op(T, V[pp ^ 1], i - 16);
+                    }
+                    if (i < 16 && (i & 1) == 0) {
+                        const int k = i >> 1;
+                        if (k < 4) W2_ULOAD(uq[pp ^ 1][k], wl0, wn, (k & 3) * 1024);
+                        else W2_ULOAD(uq[pp ^ 1][k], wl1, wn, (k & 3) * 1024);
+                    }
+                    if (st + 2 < STEPS && i >= 8 && i < 16) {  // two rows per group (one ds_read2_b64), right after the
+                        d[2 * (i - 8)] = row_read(bufc, st + 2, 2 * (i - 8));          // T ops released d: the data is
+                        d[2 * (i - 8) + 1] = row_read(bufc, st + 2, 2 * (i - 8) + 1);  // needed 16 MFMAs later
+                    }
+                    if ((st & 1) == 0 && st < 10) {
+                        const int rng = wave + 4 * (st >> 1);
+                        if (i == 15) dl = dma_decode(nxt, nch_eff, rng);
+                        if (i >= 16 && i < 20) dma_issue(dl, rng, i - 16, bufn);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    V[0 * 4 + b] = T[0 * 4 + b] - T[2 * 4 + b];
-                    V[1 * 4 + b] = T[1 * 4 + b] + T[2 * 4 + b];
-                    V[2 * 4 + b] = T[2 * 4 + b] - T[1 * 4 + b];
-                    V[3 * 4 + b] = T[1 * 4 + b] - T[3 * 4 + b];
-                }
-                if (st + 1 < STEPS) {
-                    const int nq = (st + 1) / 3, ndx = (st + 1) - nq * 3;
-                    const int off = nq * plane + ndx * 4;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) d[a * 4 + b] = *(const f32x2 *)(bufc + a_base + off + (a * IY + b) * IX * 4);
-                }
-                // this step's weights: everything older than the brick DMAs of the previous step must have landed
-                // (those 4 DMAs were issued after the weight loads and may stay in flight: they get two steps)
-                if (st > 0 && ((st - 1) & 1) == 0 && st - 1 < 10) W2_UWAIT(u[st & 1], 4);
-                else W2_UWAIT(u[st & 1], 0);
-                {
-                    const float *wn = (st + 1 < STEPS) ? wch + (size_t)(st + 1) * (16 * 128) : wnx;
-                    W2_ULOAD8(u[(st + 1) & 1], 0, wl0, wn);
-                    W2_ULOAD8(u[(st + 1) & 1], 8, wl1, wn);
-                }
-                // (without a next chunk the DMAs re-stage the current one into the idle buffer: the wait counts stay fixed)
-                if ((st & 1) == 0 && st < 10) stage_dma4(nxt, nch_eff, wave + 4 * (st >> 1), bufn);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int f = 0; f < 16; ++f)
-                        acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[st & 1][f][j], V[f][j], acc[f], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);  // keep step s+2's fetches out of step s: the 256 arch VGPRs are the limit
             }
             __syncthreads();  // retires this chunk's DMA (vmcnt(0)) and orders it before the next chunk's ds_reads
             buf ^= 1;
         }
-        W2_UWAIT(u[0], 0);  // the next tile's first fragments are in flight: settle them before the epilogue may spill them
+        W2_UWAIT(uq[0], 0);  // the next tile's first fragments are in flight: settle them before the epilogue may spill them
 
         // Y = A^T M A: along y within each z component, then along z; rows ordered mf = 2*zrow + yrow
         f32x16 out[4][1];
@@ -913,7 +935,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                             /*sync_before_red=*/false);
         cur = nxt_tile;
     }
-#undef W2_ULOAD8
+#undef W2_ULOAD
 #undef W2_UWAIT
 }
 
@@ -952,7 +974,7 @@ static void pack_conv_weights_wino(const float *w, int cin, int cin_pad, int cou
                             }
 }
 
-// 2-D Winograd pack (floats): [cout block of 32][chunk of 16][step = q*3+dx][f = fz*4+fy][lane][j 0..1] with
+// 2-D Winograd pack (floats): [cout block of 32][chunk of 16][step = q*3+dx][f/2][lane][f&1][j 0..1], f = fz*4+fy, with
 //   cout = block*32 + (lane&31), cin = chunk*16 + q*4 + (lane>>5)*2 + j, U = G w G^T over the (dz, dy) taps.
 static void pack_conv_weights_wino2(const float *w, int cin, int cin_pad, int cout, std::vector<float> &out) {
     const int nchunks = cin_pad / 16, nblk = cout / 32;
@@ -962,9 +984,10 @@ static void pack_conv_weights_wino2(const float *w, int cin, int cin_pad, int co
     for (int b = 0; b < nblk; ++b)
         for (int ch = 0; ch < nchunks; ++ch)
             for (int st = 0; st < 12; ++st)
-                for (int f = 0; f < 16; ++f)
+                for (int fp = 0; fp < 8; ++fp)
                     for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 2; ++j, ++o) {
+                        for (int fj = 0; fj < 4; ++fj, ++o) {
+                            const int f = fp * 2 + (fj >> 1), j = fj & 1;
                             const int co = b * 32 + (lane & 31);
                             const int q = st / 3, dx = st % 3;
                             const int ci = ch * 16 + q * 4 + (lane >> 5) * 2 + j;
