@@ -750,34 +750,49 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
     };
     // LDS-DMA of slots [q*BV + 64*rng, +64) of `buf`: slot i holds channel quad i / BV of brick voxel i % BV (the tail
     // of range 19 runs into the next plane with exactly the data that belongs there; past the last plane into padding).
-    // dma_decode: this lane's voxel of a 64-voxel range (recomputed at every call on purpose: hoisted out of the tile
-    // loop the decode costs 60 VGPRs that do not exist here); dma_issue: one quad of that range.
-    struct DmaLane { const float *src; unsigned voff; int over; bool in_vol; };
-    auto dma_decode = [&](const TileCoord &tc, int ch, int rng) {
-        DmaLane dl;
+    // Every VALU instruction in the tap loop costs the matrix pipe 5-10 cycles (tools/coissue_probe.hip), so the
+    // lane's part of the address is kept per range as one packed dword (rz | ry << 4 | bx << 8 | over << 16): a DMA
+    // group is ~15 VALU ops + 4 DMAs whose quad offset is the instruction's immediate (the immediate is added to the
+    // global AND the LDS address, so the LDS base is moved back by as much).
+    unsigned dma_pk[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int bv = (wave + 4 * k) * 64 + lane;
+        const int over = bv >= BV ? 1 : 0;  // tail of range 19: slots of the NEXT quad plane, voxels 0..55
+        bv -= over * BV;
+        const int rr = bv / IX, bx = bv - rr * IX;
+        const int rz = rr / IY, ry = rr - rz * IY;
+        dma_pk[k] = (unsigned)(rz | (ry << 4) | (bx << 8) | (over << 16));
+    }
+    auto dma_group = [&](const TileCoord &tc, int ch, int k, float *buf) {
+        const int rng = wave + 4 * k;
         const int cglob = ch * 16;
         const float *src; int Csrc, coff;
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
-        dl.src = src + (size_t)tc.n * p.Di * p.Hi * p.Wi * Csrc + coff;  // wave-uniform; the per-lane part fits 32 bits (host check)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        int bv = rng * 64 + ln;
-        dl.over = bv >= BV ? 1 : 0;  // tail of range 19: slots of the NEXT quad plane, voxels 0..55
-        bv -= dl.over * BV;
-        const int rr = bv / IX, bx = bv - rr * IX;
-        const int rz = rr / IY, ry = rr - rz * IY;
-        const int iz = tc.oz0 - 1 + rz, iy = tc.oy0 - 1 + ry, ix = tc.ox0 - 1 + bx;
-        dl.in_vol = ((unsigned)iz < (unsigned)p.Di) && ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
-        dl.voff = (unsigned)(((iz * p.Hi + iy) * p.Wi + ix) * Csrc + dl.over * 4);
-        return dl;
-    };
-    auto dma_issue = [&](const DmaLane &dl, int rng, int q, float *buf) {
-        const bool inside = dl.in_vol && (q + dl.over < 4);
-        const float *g = inside ? dl.src + dl.voff + q * 4 : pa.zeros;
+        // wave-uniform part (SALU); the per-lane part fits 32 bits (host check)
+        src += ((((size_t)tc.n * p.Di + (tc.oz0 - 1)) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1)) * (long)Csrc + coff;
+        const unsigned pk = dma_pk[k];
+        const int rz = pk & 15, ry = (pk >> 4) & 15, bx = (pk >> 8) & 255, over = pk >> 16;
+        const bool in_vol = ((unsigned)(tc.oz0 - 1 + rz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + ry) < (unsigned)p.Hi) &&
+                            ((unsigned)(tc.ox0 - 1 + bx) < (unsigned)p.Wi);
+        const int voff = ((rz * p.Hi + ry) * p.Wi + bx) * Csrc + over * 4;
+        const float *g = in_vol ? src + voff : pa.zeros;  // the zero page holds 4 quads
         asm volatile("" : "+v"(g));  // one DMA per quad for every lane (a branchy select would issue two and break the vmcnt count)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)(buf + (q * BV + rng * 64) * 4), 16, 0, 0);
+        float *dst = buf + rng * 64 * 4;
+        const float *g3 = g;
+        if (k == 4) {  // quad 3 of the last range: its overrun lanes fill padding; keep them inside the tensor
+            g3 = (over != 0) ? pa.zeros : g;
+            asm volatile("" : "+v"(g3));
+        }
+#define W2_DMA(G, Q)                                                                                    \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(G),              \
+                                     (__attribute__((address_space(3))) void *)(dst + (Q) * (BV * 4 - 4)), 16, (Q) * 16, 0)
+        W2_DMA(g, 0);
+        W2_DMA(g, 1);
+        W2_DMA(g, 2);
+        W2_DMA(g3, 3);
+#undef W2_DMA
     };
 
     // floats: block row (0,0) at dx = 0, quad 0, this lane's channel pair
@@ -800,11 +815,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
 
     TileCoord cur = decode(tile);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const DmaLane dl = dma_decode(cur, 0, wave + 4 * k);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dma_issue(dl, wave + 4 * k, q, lds);
-    }
+    for (int k = 0; k < 5; ++k) dma_group(cur, 0, k, lds);
     f32x4 uq[2][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -872,7 +883,6 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
             // One step = 32 MFMAs (64 cycles each); everything else of the pipeline is dealt out between them, one
             // scheduling fence per MFMA: the transform of step st+1 (its rows were read during step st-1), the weight
             // loads of step st+1, the row reads of step st+2 and, on even steps, 4 brick DMAs of the next chunk.
-            DmaLane dl;
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 const int pp = st & 1;
@@ -898,11 +908,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                         d[2 * (i - 8)] = row_read(bufc, st + 2, 2 * (i - 8));          // T ops released d: the data is
                         d[2 * (i - 8) + 1] = row_read(bufc, st + 2, 2 * (i - 8) + 1);  // needed 16 MFMAs later
                     }
-                    if ((st & 1) == 0 && st < 10) {
-                        const int rng = wave + 4 * (st >> 1);
-                        if (i == 15) dl = dma_decode(nxt, nch_eff, rng);
-                        if (i >= 16 && i < 20) dma_issue(dl, rng, i - 16, bufn);
-                    }
+                    if ((st & 1) == 0 && st < 10 && i == 16) dma_group(nxt, nch_eff, st >> 1, bufn);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
