@@ -119,7 +119,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
                     float x = acc[mf][nf][4 * g + k] + bias[k];
                     if (p.act == ACT_LRELU) x = x > 0.f ? x : x * p.slope;
                     val[k] = x;
-                    if (ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
+                    if (p.stats && ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
                 }
                 if (ok) *(f32x4 *)(orow + nf * 32 + 8 * g) = val;
             }
@@ -917,20 +917,25 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
         }
         W2_UWAIT(uq[0], 0);  // the next tile's first fragments are in flight: settle them before the epilogue may spill them
 
-        // Y = A^T M A: along y within each z component, then along z; rows ordered mf = 2*zrow + yrow
+        // Y = A^T M A: along y within each z component, then along z; rows ordered mf = 2*zrow + yrow (packed over
+        // accumulator register pairs: the epilogue is pure VALU time on a SIMD that has nothing else to run)
         f32x16 out[4][1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float P[4][2];
+        for (int r = 0; r < 16; r += 2) {
+            f32x2 P[4][2];
 #pragma unroll
             for (int fz = 0; fz < 4; ++fz) {
-                P[fz][0] = acc[fz * 4 + 0][r] + acc[fz * 4 + 1][r] + acc[fz * 4 + 2][r];
-                P[fz][1] = acc[fz * 4 + 1][r] - acc[fz * 4 + 2][r] - acc[fz * 4 + 3][r];
+                const f32x2 a0 = {acc[fz * 4 + 0][r], acc[fz * 4 + 0][r + 1]}, a1 = {acc[fz * 4 + 1][r], acc[fz * 4 + 1][r + 1]};
+                const f32x2 a2 = {acc[fz * 4 + 2][r], acc[fz * 4 + 2][r + 1]}, a3 = {acc[fz * 4 + 3][r], acc[fz * 4 + 3][r + 1]};
+                P[fz][0] = pk_add(pk_add(a0, a1), a2);
+                P[fz][1] = pk_sub(pk_sub(a1, a2), a3);
             }
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy) {
-                out[0 + yy][0][r] = P[0][yy] + P[1][yy] + P[2][yy];
-                out[2 + yy][0][r] = P[1][yy] - P[2][yy] - P[3][yy];
+                const f32x2 o0 = pk_add(pk_add(P[0][yy], P[1][yy]), P[2][yy]);
+                const f32x2 o1 = pk_sub(pk_sub(P[1][yy], P[2][yy]), P[3][yy]);
+                out[0 + yy][0][r] = o0[0]; out[0 + yy][0][r + 1] = o0[1];
+                out[2 + yy][0][r] = o1[0]; out[2 + yy][0][r + 1] = o1[1];
             }
         }
         // shared epilogue with a 2-row y tile: it places fragment mf of wave w at z = 2w + (mf>>1), y = mf&1, so
