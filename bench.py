@@ -138,8 +138,16 @@ def main():
         except Exception:
             traffic = None
     peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_F16_MFMA_TFLOPS
+    # Winograd kernels execute fewer multiplies than the algorithmic (direct-convolution) count that `achieved` uses:
+    # F(2,3) along y issues 2/3 of the direct MFMAs, F(2x2,3x3) over (z,y) 4/9; frac can therefore exceed 1 and
+    # frac_executed = matrix-pipe utilisation is reported beside it.
+    executed_ratio = {"conv3_f32_wino_kernel": 2.0 / 3.0, "conv3_f32_wino2_kernel": 4.0 / 9.0}.get(dom_name, 1.0)
+    if args.config != 2 or args.batch_tiles:
+        traffic = None  # the committed PMC passes were taken on the default workload's launch sizes
     roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved_tflops, 2), peak=peak,
                     unit="TFLOP/s", frac=round(achieved_tflops / peak, 4), traffic=traffic,
+                    executed_flop_ratio=round(executed_ratio, 4),
+                    frac_executed=round(achieved_tflops * executed_ratio / peak, 4),
                     launches=dom["launches"], avg_launch_ms=round(avg_ms, 4),
                     algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3),
                     algorithmic_mb_per_launch=round(dom["bytes"] / dom["launches"] / 1e6, 2),

@@ -61,8 +61,16 @@ def test_forward_128_model_a(amd, gpu):
     assert net.flops((128, 128, 128)) == unet_ref.conv_flops(sd, (128, 128, 128)) == net.topology.conv_flops((128, 128, 128))
     x = np.random.RandomState(2).standard_normal((1, 4, 128, 128, 128)).astype(np.float32)
     ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm="batch")).numpy()
+    net.profile(True)
     got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
+    kernels = {e["name"] for e in net.read_profile()}
+    net.profile(False)
     _check_logits(got, ref)
+    # the large stride-1 layers of this forward run on the Winograd F(2x2,3x3) kernel (default MI355_WINOGRAD=2): the
+    # tolerance above is therefore the Winograd path's tolerance, not only the direct kernels'
+    import os
+    if os.environ.get("MI355_WINOGRAD", "2") not in ("0", "1") and os.environ.get("MI355_CONV_IMPL") is None:
+        assert "conv3_f32_wino2_kernel" in kernels, sorted(kernels)
 
 
 def _small_net(amd, norm="batch", seed=21):
