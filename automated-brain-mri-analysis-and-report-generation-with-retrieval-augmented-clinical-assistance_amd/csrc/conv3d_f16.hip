@@ -320,10 +320,14 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         tc.oz0 = tile_z << p.lz; tc.oy0 = tile_y << p.ly; tc.ox0 = tile_x << p.lx;
         return tc;
     };
-    // Tile-invariant part of every staging slot, computed once per kernel: the element offset of the piece
-    // relative to the brick origin voxel (32-bit, per lane) and the brick faces it lies on (bit 0/1: z lo/hi,
-    // 2/3: y, 4/5: x; -1 = unused slot).  Per chunk a fetch then costs one AND, one compare, one select.
-    int st_pk[SLOTS];  // relative voxel offset (24 bits) | face bits << 24, or -1
+    // Tile-invariant part of every staging slot, computed once per kernel: the voxel offset of the piece relative to
+    // the brick origin voxel (24 bits, per lane) and the brick faces it lies on (bit 0/1: z lo/hi, 2/3: y, 4/5: x;
+    // bit 6 = unused slot).  A fetch is then five VALU ops: AND + compare (faces), AND + 24-bit multiply-add (byte
+    // offset), one select - the fetch itself is a raw BUFFER load from a descriptor based at the brick origin, and an
+    // out-of-volume piece gets the offset 0xffffffff: the hardware range check returns zeros, so neither a 64-bit
+    // address select nor a select on the loaded value is needed.  (VALU instructions are what the tap loop pays
+    // for: each one costs the matrix pipe 5-10 cycles, tools/coissue_probe.hip.)
+    int st_pk[SLOTS];  // relative voxel offset (24 bits) | face bits << 24
     const int Cs0 = p.C0;  // relative offsets are kept for in0's channel stride; in1 (concat half) rescales below
 #pragma unroll
     for (int r = 0; r < SLOTS; ++r) {
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         const int rel = (bz * p.Hi + by) * p.Wi + bx;   // in voxels (< 2^24: checked on the host)
         const int face = (bz == 0) | ((bz == p.IZ - 1) << 1) | ((by == 0) << 2) | ((by == IY - 1) << 3) | ((bx == 0) << 4) |
                          ((bx == IX - 1) << 5);
-        st_pk[r] = (i < npieces) ? (rel | (face << 24)) : -1;
+        st_pk[r] = (i < npieces) ? (rel | (face << 24)) : (64 << 24);
     }
     (void)Cs0;
     // which faces of the brick of tile tc stick out of the volume (wave-uniform)
@@ -349,32 +353,35 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
     auto tile_ragged = [&](const TileCoord &tc) {
         return (tc.oz0 + (1 << p.lz) > p.Di) | (tc.oy0 + (1 << p.ly) > p.Hi) | (tc.ox0 + (1 << p.lx) > p.Wi);
     };
-    auto stage_issue = [&](const TileCoord &tc, int faces, bool ragged, int ch, int r, int &dst, bool &inside) {
+    const int dst0 = (tid & 1) * p.plane_bytes + (tid >> 1) * 16;  // LDS byte offset of slot 0; slot r is 128 voxels further
+    auto stage_issue = [&](const TileCoord &tc, int faces, bool ragged, int ch, int r) {
         const int cglob = ch * 16;
         const half_t *src; int Csrc, coff;
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
-        const int i = r * 256 + tid;
         const int pk = st_pk[r];
-        const int face = pk >> 24;  // -1 for an unused slot
-        dst = (pk >= 0) ? (i & 1) * p.plane_bytes + (i >> 1) * 16 : -1;
-        inside = (pk >= 0) && ((face & faces) == 0);
+        bool inside = (pk & ((faces | 64) << 24)) == 0;
         if (ragged) {  // rare: tile overhangs the volume by more than the halo -> exact per-axis test
-            const int bv = i >> 1;
+            const int bv = (r * 256 + tid) >> 1;
             const int rr = (int)fdiv((uint32_t)bv, p.div_IX);
             const int bx = bv - rr * IX;
             const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
             const int by = rr - bz * IY;
-            inside = (pk >= 0) && ((unsigned)(tc.oz0 - 1 + bz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + by) < (unsigned)p.Hi) &&
+            inside = ((pk >> 30) == 0) && ((unsigned)(tc.oz0 - 1 + bz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + by) < (unsigned)p.Hi) &&
                      ((unsigned)(tc.ox0 - 1 + bx) < (unsigned)p.Wi);
         }
-        // wave-uniform base of the brick origin voxel (may lie one voxel outside the tensor: only used when inside)
+        // wave-uniform descriptor based at the brick origin voxel (may lie one voxel outside the tensor: only pieces
+        // inside the volume are addressed through it)
         const long base_vox = (((long)tc.n * p.Di + (tc.oz0 - 1)) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1);
         const half_t *sbase = src + base_vox * Csrc + coff;
-        const int rel = inside ? (pk & 0xffffff) * Csrc + qoff : 0;
-        const half_t *ptr = inside ? sbase + rel : src;
-        return *(const f32x4 *)ptr;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sbase, 0, 0x7fffffff, 0x00020000);
+        const unsigned off = __umul24((unsigned)pk & 0xffffffu, (unsigned)(Csrc * 2)) + qoff * 2;
+        const unsigned voff = inside ? off : 0xffffffffu;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+        return __builtin_bit_cast(f32x4, v);
     };
+    auto slot_valid = [&](int r) { return (st_pk[r] >> 30) == 0; };
 
     f32x16 acc[MF][NF];
     acc_init_bias<MF, NF>(acc, p.bias, (int)blockIdx.y * NF * 32, half);
@@ -383,14 +390,12 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
     const half_t *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512);
     const int wlane = lane * 8;
     const int co_blk = (int)blockIdx.y * NF * 32;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     TileCoord cur = decode(tile);
 #pragma unroll
     for (int r = 0; r < SLOTS; ++r) {
-        bool inside; int dst;
-        const f32x4 v = stage_issue(cur, tile_faces(cur), tile_ragged(cur), 0, r, dst, inside);
-        if (dst >= 0) *(f32x4 *)(lds_raw + dst) = inside ? v : zero4;
+        const f32x4 v = stage_issue(cur, tile_faces(cur), tile_ragged(cur), 0, r);
+        if (slot_valid(r)) *(f32x4 *)(lds_raw + dst0 + r * 2048) = v;
     }
     f16x8 bq[BD][NF];
 #pragma unroll
@@ -417,8 +422,6 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) a[0][mf] = *(const f16x8 *)(bufc + a_base[mf]);
         f32x4 st_v[SLOTS];
-        int st_dst[SLOTS];
-        bool st_in[SLOTS];
 
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) bnew[nf] = (ABL & 2) ? bq[tap % BD][nf] : *(const f16x8 *)(wsrc + nf * 512 + wlane);
             }
-            if (!(ABL & 4) && tap < SLOTS) st_v[tap] = stage_issue(nxt, nfaces, nragged, nch_eff, tap, st_dst[tap], st_in[tap]);
+            if (!(ABL & 4) && tap < SLOTS) st_v[tap] = stage_issue(nxt, nfaces, nragged, nch_eff, tap);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
             for (int r = 0; r < SLOTS; ++r) {
                 const int wr = r + FLIGHT < 26 ? r + FLIGHT : 26;
-                if (!(ABL & 4) && wr == tap && have_next && st_dst[r] >= 0) *(f32x4 *)(bufn + st_dst[r]) = st_in[r] ? st_v[r] : zero4;
+                if (!(ABL & 4) && wr == tap && have_next && slot_valid(r)) *(f32x4 *)(bufn + dst0 + r * 2048) = st_v[r];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
