@@ -388,7 +388,14 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 
     // wave-uniform weight base (SGPRs) + a 32-bit per-lane offset: the tap / chunk offsets are scalar arithmetic
     const half_t *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512);
-    const int wlane = lane * 8;
+    // weights: raw buffer loads, per-lane offset in a VGPR that never changes, tap / chunk offset in an SGPR (soffset):
+    // no VALU address arithmetic in the tap loop
+    const unsigned wlane = lane * 16;
+    typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wblk, 0, 0x7fffffff, 0x00020000);
+    auto wload = [&](unsigned soff_halfs) {
+        return __builtin_bit_cast(f16x8, (wu32x4)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, soff_halfs * 2, 0));
+    };
     const int co_blk = (int)blockIdx.y * NF * 32;
 
     TileCoord cur = decode(tile);
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
     for (int k = 0; k < BD; ++k)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) bq[k][nf] = *(const f16x8 *)(wblk + (size_t)k * (NF * 512) + nf * 512 + wlane);
+        for (int nf = 0; nf < NF; ++nf) bq[k][nf] = wload(k * (NF * 512) + nf * 512);
     __syncthreads();
 
     int ch = 0, buf = 0;
@@ -415,12 +422,21 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         const bool nragged = tile_ragged(nxt);
         const char *bufc = lds_raw + buf * buf_bytes;
         char *bufn = lds_raw + (buf ^ 1) * buf_bytes;
-        const half_t *wch = wblk + (size_t)ch * (27 * NF * 512);
-        const half_t *wnx = wblk + (size_t)nch_eff * (27 * NF * 512);
+        const unsigned wch = ch * (27 * NF * 512), wnx = nch_eff * (27 * NF * 512);  // halfs from wblk
 
+        // per-chunk LDS addresses of the voxel fragments, pinned in VGPRs: the 27 tap offsets are instruction immediates
+        typedef const __attribute__((address_space(3))) char lds_cchar;
+        typedef const __attribute__((address_space(3))) f16x8 lds_cf16x8;
+        lds_cchar *ab[MF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            unsigned t = (unsigned)(size_t)(lds_cchar *)bufc + a_base[mf];
+            asm volatile("" : "+v"(t));
+            ab[mf] = (lds_cchar *)t;
+        }
         f16x8 a[2][MF];
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) a[0][mf] = *(const f16x8 *)(bufc + a_base[mf]);
+        for (int mf = 0; mf < MF; ++mf) a[0][mf] = *(lds_cf16x8 *)(ab[mf]);
         f32x4 st_v[SLOTS];
 
 #pragma unroll
@@ -434,13 +450,13 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
                 const int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
                 const int off = ((dz * IY + dy) * IX + dx) * 16;
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf) a[(tap + 1) & 1][mf] = (ABL & 1) ? a[tap & 1][mf] : *(const f16x8 *)(bufc + a_base[mf] + off);
+                for (int mf = 0; mf < MF; ++mf) a[(tap + 1) & 1][mf] = (ABL & 1) ? a[tap & 1][mf] : *(lds_cf16x8 *)(ab[mf] + off);
             }
             {
                 const int k = tap + BD;
-                const half_t *wsrc = (k < 27) ? wch + (size_t)k * (NF * 512) : wnx + (size_t)(k - 27) * (NF * 512);
+                const unsigned wsrc = (k < 27) ? wch + k * (NF * 512) : wnx + (k - 27) * (NF * 512);
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf) bnew[nf] = (ABL & 2) ? bq[tap % BD][nf] : *(const f16x8 *)(wsrc + nf * 512 + wlane);
+                for (int nf = 0; nf < NF; ++nf) bnew[nf] = (ABL & 2) ? bq[tap % BD][nf] : wload(wsrc + nf * 512);
             }
             if (!(ABL & 4) && tap < SLOTS) st_v[tap] = stage_issue(nxt, nfaces, nragged, nch_eff, tap);
             __builtin_amdgcn_sched_barrier(0);
