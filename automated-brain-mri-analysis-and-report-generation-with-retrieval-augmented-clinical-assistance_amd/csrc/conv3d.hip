@@ -50,7 +50,7 @@ struct ConvArgs {
 // 4 stores per 32x32 tile instead of 16 dword stores (the store tail is issue-bound, not bandwidth-bound).
 // Adds bias, optional LeakyReLU, predicated on the volume bounds; optional per-(n, cout) sum / sum of squares:
 // butterfly over the 32 voxel lanes, then LDS across the 4 waves, then one fp64 atomic per cout.
-template <int MF, int NF>
+template <int MF, int NF, int NW = 4>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvArgs &p, int n, int oz0, int oy0,
                                               int ox0, int co_blk, float *red, bool sync_before_red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -145,7 +145,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
             const int c = tid >> 1, k = tid & 1;
             double tot = 0.0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
+            for (int w = 0; w < NW; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
             atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, tot);
         }
     }
