@@ -160,9 +160,11 @@ def calculate_volumes(seg_path):
             "TC": (ncr + et) * voxel_volume_cm3, "WT": (ncr + ed + et) * voxel_volume_cm3}
 
 
-def ensemble_label_files(model1_output: Path, model2_output: Path, output_folder: Path):
-    """Reference :286-322: np.round((seg1 + seg2) / 2) per voxel, saved with seg1's header."""
+def ensemble_label_files(model1_output: Path, model2_output: Path, output_folder: Path, label_format: str = "nnunet"):
+    """Reference :286-322: np.round((seg1 + seg2) / 2) per voxel, saved with seg1's header.  `label_format` other
+    than "nnunet" folds convert_labels_to_brats.py:34-55 into the export (the label map is still on the device)."""
     import torch
+    from . import evaluate
     finals = []
     for seg1_path in sorted(model1_output.glob("*.nii.gz")):
         case_name = seg1_path.stem.replace(".nii", "")
@@ -174,7 +176,7 @@ def ensemble_label_files(model1_output: Path, model2_output: Path, output_folder
         img1, img2 = nifti.load(seg1_path), nifti.load(seg2_path)
         a = torch.from_numpy(np.ascontiguousarray(img1.data.astype(np.uint8))).cuda()
         b = torch.from_numpy(np.ascontiguousarray(img2.data.astype(np.uint8))).cuda()
-        ens = ops.label_ensemble(a, b).cpu().numpy()
+        ens = evaluate.convert_labels(ops.label_ensemble(a, b), label_format).cpu().numpy()
         final_output = output_folder / f"{case_name}.nii.gz"
         nifti.save_like(final_output, ens, img1)
         print(f"[OK] Saved: {final_output}")
@@ -199,6 +201,9 @@ def main(argv=None, script_dir=None):
     ap.add_argument("--folds", type=int, nargs="+", default=[0, 1, 2, 3, 4])
     ap.add_argument("--disable_tta", action="store_true")
     ap.add_argument("--step_size", type=float, default=0.5)
+    ap.add_argument("--label-format", dest="label_format", choices=("nnunet", "brats2025", "brats2021"), default="nnunet",
+                    help="convention of the final <case>.nii.gz; 'nnunet' (default) is what the reference writes, the others "
+                         "fold convert_labels_to_brats.py:34-55 into the export")
     args = ap.parse_args(argv)
     script_dir = Path(script_dir) if script_dir else Path(__file__).resolve().parent.parent
     results_folder = Path(args.results_folder or os.environ.get("MI355_RESULTS_FOLDER") or script_dir / "nnUNet_results")
@@ -214,7 +219,7 @@ def main(argv=None, script_dir=None):
         run_model_single_threaded(base / name, args.input, outs[-1], tuple(args.folds), not args.disable_tta,
                                   args.step_size)
     print("\n" + "=" * 70 + "\nENSEMBLING MODEL PREDICTIONS\n" + "=" * 70)
-    ensemble_label_files(outs[0], outs[1], output_folder)
+    ensemble_label_files(outs[0], outs[1], output_folder, args.label_format)
     print("\n" + "=" * 70 + "\nSEGMENTATION COMPLETE!\n" + "=" * 70)
     print(f"Results saved to: {output_folder}")
     return 0

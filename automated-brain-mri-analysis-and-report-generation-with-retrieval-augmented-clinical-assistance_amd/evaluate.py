@@ -40,6 +40,24 @@ def convert_labels(seg, fmt="brats2025"):
     return out
 
 
+def apply_brats_threshold(seg, threshold=200, replace_with=2):
+    """KAIST post-processing (archived/kaist_original_inference.py:33, ``apply_threshold_to_folder(..., 200, 2)``):
+    a case with fewer than `threshold` voxels of label 3 (enhancing tumour) gets them relabelled to `replace_with`.
+    seg: CUDA uint8 label map.  Returns (new label map, number of label-3 voxels found)."""
+    n3 = int(confusion(seg, seg, num_labels=4)[3, 3])  # one device pass over the label map
+    if n3 >= threshold:
+        return seg.clone(), n3
+    import torch
+    table = np.arange(256, dtype=np.uint8)
+    table[3] = replace_with
+    seg = seg.contiguous()
+    out = torch.empty_like(seg)
+    stream = torch.cuda.current_stream(seg.device).cuda_stream
+    _lib.check(_lib.load().mi355_label_remap(seg.data_ptr(), out.data_ptr(), seg.numel(),
+                                             table.ctypes.data_as(C.POINTER(C.c_uint8)), stream), "mi355_label_remap")
+    return out, n3
+
+
 def confusion(pred, gt, num_labels=5):
     """K x K integer matrix, rows = predicted label, columns = ground truth."""
     import torch

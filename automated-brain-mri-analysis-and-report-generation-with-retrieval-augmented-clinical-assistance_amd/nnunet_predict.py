@@ -5,6 +5,9 @@ Surface per archived/kaist_original_inference.py:30-32 and scripts/run_inference
     python -m brats_amd.nnunet_predict -i IN -o OUT -t 500 -m 3d_fullres -tr <trainer> [-f 0 1 ..]
            [--save_npz] [--disable_tta] [--step_size 0.5] [-p nnUNetPlansv2.1]
     python -m brats_amd.nnunet_predict --ensemble OUT1 OUT2 -o OUT        (probability mean of the npz files)
+    python -m brats_amd.nnunet_predict --postprocess FOLDER -o OUT [--threshold 200 --replace_with 2]
+           [--label_format nnunet|brats2025|brats2021]                     (kaist_original_inference.py:33-34)
+    python -m brats_amd.nnunet_predict --kaist -i IN -o OUT [-f ...]       (the whole script :26-38 in one process)
 
 IN holds nnU-Net-named files ``<case>_0000..0003.nii.gz``; RESULTS_FOLDER locates the models.
 """
@@ -37,9 +40,42 @@ def main(argv=None):
     ap.add_argument("--disable_tta", action="store_true")
     ap.add_argument("--step_size", type=float, default=0.5)
     ap.add_argument("--ensemble", nargs=2, metavar=("FOLDER1", "FOLDER2"))
+    ap.add_argument("--postprocess", metavar="FOLDER", help="apply_threshold_to_folder + label convention on label NIfTIs")
+    ap.add_argument("--threshold", type=int, default=200)
+    ap.add_argument("--replace_with", type=int, default=2)
+    ap.add_argument("--label_format", choices=("nnunet", "brats2025", "brats2021"), default=None,
+                    help="default: brats2021 for --postprocess / --kaist (the 2018/2019 convention of the KAIST script)")
+    ap.add_argument("--kaist", action="store_true", help="both trainers + probability ensemble + post-processing")
     args = ap.parse_args(argv)
     out = Path(args.output_folder)
     out.mkdir(parents=True, exist_ok=True)
+    if args.kaist:
+        if not args.input_folder:
+            ap.error("-i is required")
+        common = ["-t", args.task_name, "-m", args.model, "-p", args.plans_identifier, "--step_size", str(args.step_size),
+                  "-f", *[str(k) for k in args.folds]] + (["--disable_tta"] if args.disable_tta else [])
+        raw = []
+        for k, tr in enumerate((driver.MODEL1, driver.MODEL2), 1):
+            raw.append(out / f"raw_output_{k}")
+            rc = main(["-i", args.input_folder, "-o", str(raw[-1]), "-tr", tr.split("__")[0], "--save_npz", *common])
+            if rc:
+                return rc
+        rc = main(["--ensemble", str(raw[0]), str(raw[1]), "-o", str(out / "ensemble")])
+        if rc:
+            return rc
+        return main(["--postprocess", str(out / "ensemble"), "-o", str(out), "--threshold", str(args.threshold),
+                     "--replace_with", str(args.replace_with), "--label_format", args.label_format or "brats2021"])
+    if args.postprocess:
+        import torch
+        from . import evaluate
+        for fpath in sorted(Path(args.postprocess).glob("*.nii.gz")):
+            like = nifti.load(fpath)
+            seg = torch.from_numpy(np.ascontiguousarray(like.data.astype(np.uint8))).cuda()
+            seg, n3 = evaluate.apply_brats_threshold(seg, args.threshold, args.replace_with)
+            seg = evaluate.convert_labels(seg, args.label_format or "brats2021")
+            nifti.save_like(out / fpath.name, seg.cpu().numpy(), like)
+            print(f"[OK] {out / fpath.name} (enhancing voxels: {n3}{', relabelled' if n3 < args.threshold else ''})")
+        return 0
     if args.ensemble:
         import torch
         f1, f2 = (Path(p) for p in args.ensemble)

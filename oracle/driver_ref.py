@@ -34,3 +34,26 @@ def predict_case(raw_zyx, fold_state_dicts, cfg, patch, do_tta=True, step_size=0
     seg = tiler_ref.regions_to_labels(probs, (1, 2, 3))
     full = tiler_ref.paste_into_original(seg, props["crop_bbox"], props["original_size_of_raw_data"])
     return full, probs, props
+
+
+def apply_brats_threshold(seg, threshold=200, replace_with=2):
+    """archived/kaist_original_inference.py:33 -> nnunet.dataset_conversion.Task500_BraTS_2021.apply_threshold_to_folder
+    (nnU-Net v1, KAIST BraTS21 fork; un-vendored, see oracle/__init__.py: parity unpinned).  Published algorithm,
+    per file: ``s = np.sum(img == 3); if s < threshold: img[img == 3] = replace_with`` - a case with fewer than
+    `threshold` enhancing-tumour voxels has them relabelled (to label 2 at the KAIST call site)."""
+    out = np.array(seg, copy=True)
+    if int(np.sum(out == 3)) < threshold:
+        out[out == 3] = replace_with
+    return out
+
+
+def convert_labels_back_to_brats(seg):
+    """archived/kaist_original_inference.py:34 -> Task032_BraTS_2018.convert_labels_back_to_BraTS_2018_2019_convention
+    (un-vendored): ``new[seg == 1] = 2; new[seg == 3] = 4; new[seg == 2] = 1`` - identical to the in-repo
+    convert_labels_to_brats.py:46-55 (BraTS 2021 convention), which pins it."""
+    seg = np.round(seg).astype(np.uint8)
+    new = np.zeros_like(seg)
+    new[seg == 1] = 2
+    new[seg == 2] = 1
+    new[seg == 3] = 4
+    return new

@@ -110,6 +110,21 @@ def test_nnunet_predict_cli_save_npz_and_probability_ensemble(amd, gpu, tmp_path
     want = tiler_ref.paste_into_original(tiler_ref.regions_to_labels((p1 + p2) / 2.0), props["crop_bbox"],
                                          props["original_size_of_raw_data"])
     assert tiler_ref.brats_region_dice(got, want)["mean"] >= 0.999
+    # post-processing of kaist_original_inference.py:33-34 on the ensemble folder: ET threshold, then the 2018/2019
+    # label convention; once with a threshold that relabels and once with one that does not
+    for thr, name in ((10 ** 9, "pp_hi"), (0, "pp_lo")):
+        pp = tmp_path / name
+        res = subprocess.run([sys.executable, "-m", "brats_amd.nnunet_predict", "--postprocess", str(ens), "-o", str(pp),
+                              "--threshold", str(thr), "--replace_with", "2"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+        want_pp = driver_ref.convert_labels_back_to_brats(driver_ref.apply_brats_threshold(got, thr, 2))
+        assert np.array_equal(amd.nifti.load(pp / "case.nii.gz").as_zyx(), want_pp)
+    # the whole script in one call gives the same files as the three steps above
+    kaist = tmp_path / "kaist"
+    res = subprocess.run([sys.executable, "-m", "brats_amd.nnunet_predict", "--kaist", "-i", str(in_dir), "-o", str(kaist), "-f", "0",
+                          "--threshold", str(10 ** 9)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert np.array_equal(amd.nifti.load(kaist / "case.nii.gz").as_zyx(), amd.nifti.load(tmp_path / "pp_hi" / "case.nii.gz").as_zyx())
     missing = subprocess.run([sys.executable, "-m", "brats_amd.nnunet_predict", "-i", str(in_dir), "-o", str(tmp_path / "x"),
                               "-tr", "nnUNetTrainerDoesNotExist"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert missing.returncode == 1 and "[ERROR] Model not found" in missing.stdout

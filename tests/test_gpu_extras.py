@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import extras_ref
+from oracle import driver_ref, extras_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +18,22 @@ def test_convert_labels(amd, gpu, fmt):
     seg = _labels(np.random.RandomState(1), (24, 30, 28))
     got = amd.evaluate.convert_labels(torch.from_numpy(seg).to(gpu), fmt).cpu().numpy()
     assert np.array_equal(got, extras_ref.convert_labels(seg, fmt))
+
+
+@pytest.mark.parametrize("n_et,threshold", [(0, 200), (37, 200), (199, 200), (200, 200), (5000, 200), (5000, 100000)])
+def test_apply_brats_threshold(amd, gpu, n_et, threshold):
+    """KAIST post-processing (archived/kaist_original_inference.py:33): bit-exact against the oracle's restatement,
+    on both sides of the threshold, at the full raw-volume size."""
+    rs = np.random.RandomState(n_et + 1)
+    seg = _labels(rs, (155, 240, 240), (0.96, 0.02, 0.02, 0.0))
+    flat = seg.reshape(-1)
+    flat[rs.choice(flat.size, size=n_et, replace=False)] = 3
+    got, n3 = amd.evaluate.apply_brats_threshold(torch.from_numpy(seg).to(gpu), threshold, 2)
+    assert n3 == n_et
+    want = driver_ref.apply_brats_threshold(seg, threshold, 2)
+    assert np.array_equal(got.cpu().numpy(), want)
+    # followed by the label convention of :34 (= convert_labels_to_brats.py:46-55)
+    assert np.array_equal(amd.evaluate.convert_labels(got, "brats2021").cpu().numpy(), driver_ref.convert_labels_back_to_brats(want))
 
 
 def test_evaluator_matches_reference_formulas(amd, gpu):

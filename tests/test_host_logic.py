@@ -87,3 +87,20 @@ def test_product_never_imports_the_oracle():
         p = os.path.join(ROOT, f)
         if os.path.exists(p):
             assert not re.search(r"^\s*(from|import)\s+oracle\b", open(p).read(), flags=re.M)
+
+
+def test_oracle_kaist_postprocessing_truth_table():
+    """oracle/driver_ref.py: ET threshold (kaist_original_inference.py:33) and label convention (:34), on hand-made cases."""
+    import numpy as np
+    from oracle import driver_ref, extras_ref
+    seg = np.zeros((4, 5, 6), np.uint8)
+    seg[0, 0, :3] = 3
+    seg[1, 1, :4] = 1
+    seg[2, 2, :2] = 2
+    low = driver_ref.apply_brats_threshold(seg, threshold=4, replace_with=2)       # 3 voxels < 4 -> relabelled
+    assert (low == 3).sum() == 0 and (low == 2).sum() == 5 and (low == 1).sum() == 4
+    same = driver_ref.apply_brats_threshold(seg, threshold=3, replace_with=2)      # 3 voxels, not < 3 -> kept
+    assert np.array_equal(same, seg)
+    conv = driver_ref.convert_labels_back_to_brats(seg)
+    assert np.array_equal(conv, extras_ref.convert_labels(seg, "brats2021"))       # the in-repo converter pins it
+    assert set(np.unique(conv)) == {0, 1, 2, 4} and (conv == 4).sum() == 3 and (conv == 2).sum() == 4 and (conv == 1).sum() == 2
