@@ -274,9 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
 }
 
 // ------------------------------------------------------------------ pipelined persistent kernel (stride 1)
-// ABL (timing experiments only, MI355_CONV_ABLATE): 1 = no voxel-fragment LDS reads, 2 = no weight fetches,
-// 4 = no staging of the next brick (results are then wrong; only the clock matters).
-template <int MF, int NF, int ABL = 0, bool HEAD = false>
+template <int MF, int NF, bool HEAD = false>
 __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     constexpr int SLOTS = MF == 4 ? 11 : 8;  // 16-B staging pieces per thread and chunk
@@ -450,15 +448,15 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
                 const int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
                 const int off = ((dz * IY + dy) * IX + dx) * 16;
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf) a[(tap + 1) & 1][mf] = (ABL & 1) ? a[tap & 1][mf] : *(lds_cf16x8 *)(ab[mf] + off);
+                for (int mf = 0; mf < MF; ++mf) a[(tap + 1) & 1][mf] = *(lds_cf16x8 *)(ab[mf] + off);
             }
             {
                 const int k = tap + BD;
                 const unsigned wsrc = (k < 27) ? wch + k * (NF * 512) : wnx + (k - 27) * (NF * 512);
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf) bnew[nf] = (ABL & 2) ? bq[tap % BD][nf] : wload(wsrc + nf * 512);
+                for (int nf = 0; nf < NF; ++nf) bnew[nf] = wload(wsrc + nf * 512);
             }
-            if (!(ABL & 4) && tap < SLOTS) st_v[tap] = stage_issue(nxt, nfaces, nragged, nch_eff, tap);
+            if (tap < SLOTS) st_v[tap] = stage_issue(nxt, nfaces, nragged, nch_eff, tap);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
@@ -470,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
             for (int r = 0; r < SLOTS; ++r) {
                 const int wr = r + FLIGHT < 26 ? r + FLIGHT : 26;
-                if (!(ABL & 4) && wr == tap && have_next && slot_valid(r)) *(f32x4 *)(bufn + dst0 + r * 2048) = st_v[r];
+                if (wr == tap && have_next && slot_valid(r)) *(f32x4 *)(bufn + dst0 + r * 2048) = st_v[r];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -611,19 +609,13 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         const int need = (int)((tiles + 7) / 8) * 8;
         if (gx > need) gx = need;
         dim3 grid(gx, gy);
-        if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, 0, false>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, 0, false>" : "conv3_f16_mfma_pipe_kernel<2, 2, 0, false>");
-        static int abl = -1;
-        if (abl < 0) { const char *e = getenv("MI355_CONV_ABLATE"); abl = e ? atoi(e) : 0; }
-        if (MF == 4 && abl == 1) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 1>, a, grid, lds_bytes, s, &attr[7]);
-        if (MF == 4 && abl == 2) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 2>, a, grid, lds_bytes, s, &attr[7]);
-        if (MF == 4 && abl == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 4>, a, grid, lds_bytes, s, &attr[7]);
-        if (MF == 4 && abl == 7) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 7>, a, grid, lds_bytes, s, &attr[7]);
-        if (MF == 4 && abl == 6) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 6>, a, grid, lds_bytes, s, &attr[7]);
+        if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false>" : "conv3_f16_mfma_pipe_kernel<2, 2, false>");
         if (c.head_out) {
             MI355_REQUIRE(w.nf == 1, "fused head: fp16 path supports Cout = 32 only");
-            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, 0, true>" : "conv3_f16_mfma_pipe_kernel<2, 1, 0, true>";
-            if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, 0, true>, a, grid, lds_bytes, s, &attr[0]);
-            return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, 0, true>, a, grid, lds_bytes, s, &attr[1]);
+            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, true>" : "conv3_f16_mfma_pipe_kernel<2, 1, true>";
+            static size_t attr_head[2] = {48 * 1024, 48 * 1024};  // one slot per kernel: the attribute is per function
+            if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, true>, a, grid, lds_bytes, s, &attr_head[0]);
+            return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, true>, a, grid, lds_bytes, s, &attr_head[1]);
         }
         if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1>, a, grid, lds_bytes, s, &attr[0]);
         if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1>, a, grid, lds_bytes, s, &attr[1]);
