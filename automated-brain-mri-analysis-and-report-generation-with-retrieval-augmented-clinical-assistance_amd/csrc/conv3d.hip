@@ -950,6 +950,171 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
 #undef W2_UWAIT
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-2 convolution (the encoder's "convolutional pooling", generic_UNet.py:285-288,314-315) as ONE persistent
+// workgroup per CU.  What the experiments in DESIGN.md say about these layers: a 2x2x32 output tile needs a 5x5x65 input
+// brick (12.7 voxels per output), at one voxel fragment per wave every MFMA group would stream its own KiB of weights
+// through the L1, and synchronous staging is not hidden by a second workgroup.  So, with the machinery of the Winograd
+// kernel above: the 8-channel brick is double-buffered and filled by LDS-DMA while the previous chunk is computed, and
+// the weights come through LDS as well - one dz plane of the chunk (9 taps x 64 couts = 18 KiB) per step in a two-slot
+// ring, fetched by DMA one step ahead and shared by the four waves.  The tap loop then holds LDS reads and MFMAs only
+// (8 per tap: 4 channel pairs x 2 cout fragments); the VALU work left is the DMA address arithmetic.
+// Step = (chunk, dz): 72 MFMAs per wave; the barrier that ends it retires the step's DMAs (vmcnt(0)) before anybody
+// reads what they fetched.
+constexpr int S2_IX = 65, S2_IY = 5, S2_IZ = 5, S2_BV = S2_IX * S2_IY * S2_IZ;   // 1625 brick voxels, 2 quads each
+constexpr int S2_RANGES = 28, S2_RSTRIDE = 59;                                     // DMA ranges [59r, 59r + 64) per quad plane
+constexpr int S2_PAD = S2_RANGES * S2_RSTRIDE + 5 - S2_BV;                         // slots written past the last plane
+constexpr int S2_BUF_FLOATS = (2 * S2_BV + S2_PAD) * 4;
+constexpr int S2_WSLOT_FLOATS = 9 * 2 * 256;                                       // one dz plane: 9 taps x 2 cout fragments
+constexpr size_t S2_LDS_BYTES = (size_t)(2 * S2_BUF_FLOATS + 2 * S2_WSLOT_FLOATS + 4 * 64 * 2) * sizeof(float);
+
+__global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvArgs &p = pa.c;
+    constexpr int IX = S2_IX, IY = S2_IY, BV = S2_BV;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    float *wring = lds + 2 * S2_BUF_FLOATS;
+    float *red = wring + 2 * S2_WSLOT_FLOATS;
+
+    const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x - xcd + 7) >> 3;
+    const int q8 = pa.total_tiles >> 3, r8 = pa.total_tiles & 7;
+    const int lo = xcd * q8 + (xcd < r8 ? xcd : r8);
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + li;
+    if (tile >= hi) return;
+
+    struct TileCoord { int n, oz0, oy0, ox0; };
+    auto decode = [&](int t) {
+        TileCoord tc;
+        tc.n = (int)fdiv((uint32_t)t, p.div_tiles_per_n);
+        const int tt = t - tc.n * (int)p.div_tiles_per_n.d;
+        const int tzy = (int)fdiv((uint32_t)tt, p.div_tiles_x);
+        const int tile_x = tt - tzy * p.tiles_x;
+        const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
+        const int tile_y = tzy - tile_z * p.tiles_y;
+        tc.oz0 = tile_z << 1; tc.oy0 = tile_y << 1; tc.ox0 = tile_x << 5;  // tile is fixed: 2 x 2 x 32 outputs
+        return tc;
+    };
+
+    // brick DMA: 7 ranges per wave, both quads of a range back to back.  Range r = voxels [59r, 59r + 64) of a quad
+    // plane; overlaps carry identical data, the tail of range 27 runs into the next plane (or the padding).
+    unsigned dma_pk[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        int bv = (wave + 4 * k) * S2_RSTRIDE + lane;
+        const int over = bv >= BV ? 1 : 0;
+        bv -= over * BV;
+        const int rr = bv / IX, bx = bv - rr * IX;
+        const int rz = rr / IY, ry = rr - rz * IY;
+        dma_pk[k] = (unsigned)(rz | (ry << 4) | (bx << 8) | (over << 16));
+    }
+    auto dma_brick = [&](const TileCoord &tc, int ch, int k, float *buf) {
+        const int rng = wave + 4 * k;
+        const int cglob = ch * 8;
+        const float *src; int Csrc, coff;
+        if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
+        else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
+        src += ((((size_t)tc.n * p.Di + (2 * tc.oz0 - 1)) * p.Hi + (2 * tc.oy0 - 1)) * p.Wi + (2 * tc.ox0 - 1)) * (long)Csrc + coff;
+        const unsigned pk = dma_pk[k];
+        const int rz = pk & 15, ry = (pk >> 4) & 15, bx = (pk >> 8) & 255, over = pk >> 16;
+        const bool in_vol = ((unsigned)(2 * tc.oz0 - 1 + rz) < (unsigned)p.Di) && ((unsigned)(2 * tc.oy0 - 1 + ry) < (unsigned)p.Hi) &&
+                            ((unsigned)(2 * tc.ox0 - 1 + bx) < (unsigned)p.Wi);
+        const int voff = ((rz * p.Hi + ry) * p.Wi + bx) * Csrc + over * 4;
+        const float *g0 = in_vol ? src + voff : pa.zeros;
+        const float *g1 = (in_vol && over == 0) ? src + voff : pa.zeros;  // quad 1's overrun lanes fill padding
+        asm volatile("" : "+v"(g0), "+v"(g1));
+        float *dst = buf + rng * S2_RSTRIDE * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g0,
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g1,
+                                         (__attribute__((address_space(3))) void *)(dst + BV * 4 - 4), 16, 16, 0);
+    };
+    // weight DMA: dz plane `dz` of chunk `ch` = 18 KiB contiguous in the pack; KiB i goes to wave i & 3
+    const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * 2 * 256);
+    auto dma_weights = [&](int ch, int dz, float *slot) {
+        const float *wsrc = wblk + ((size_t)ch * 27 + dz * 9) * (2 * 256) + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int kib = wave + 4 * i;
+            if (kib < 18)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + kib * 256),
+                                                 (__attribute__((address_space(3))) void *)(slot + kib * 256), 16, 0, 0);
+        }
+    };
+
+    // wave w = output (z, y) = (w >> 1, w & 1) of the tile, lane = x; floats: input voxel (2z, 2y, 2x) at tap 0, quad `half`
+    const int a_base = half * BV * 4 + (((wave >> 1) * 2 * IY + (wave & 1) * 2) * IX + 2 * l31) * 4;
+
+    TileCoord cur = decode(tile);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) dma_brick(cur, 0, k, lds);
+    dma_weights(0, 0, wring);
+    __syncthreads();
+
+    int buf = 0, wslot = 0;
+    for (; tile < hi; tile += nl) {
+        f32x16 acc[1][2];
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][nf][r] = 0.f;
+        const int ntile = tile + nl;
+        const TileCoord nxt_tile = ntile < hi ? decode(ntile) : cur;
+
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const bool last_ch = ch == p.nchunks - 1;
+            const bool have_next = !last_ch || ntile < hi;
+            const TileCoord nxt = last_ch ? nxt_tile : cur;
+            const int nch = last_ch ? 0 : ch + 1;
+            const float *bufc = lds + buf * S2_BUF_FLOATS;
+            float *bufn = lds + (buf ^ 1) * S2_BUF_FLOATS;
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                // fetches of the step: the next weight plane and a third of the next chunk's brick
+                if (dz < 2) dma_weights(ch, dz + 1, wring + (wslot ^ 1) * S2_WSLOT_FLOATS);
+                else if (have_next) dma_weights(nch, 0, wring + (wslot ^ 1) * S2_WSLOT_FLOATS);
+                if (have_next) {
+                    if (dz == 0) { dma_brick(nxt, nch, 0, bufn); dma_brick(nxt, nch, 1, bufn); dma_brick(nxt, nch, 2, bufn); }
+                    else if (dz == 1) { dma_brick(nxt, nch, 3, bufn); dma_brick(nxt, nch, 4, bufn); }
+                    else { dma_brick(nxt, nch, 5, bufn); dma_brick(nxt, nch, 6, bufn); }
+                }
+                const float *wcur = wring + wslot * S2_WSLOT_FLOATS + lane * 4;
+                f32x4 a_cur, a_nxt, b_cur[2], b_nxt[2];
+                a_cur = *(const f32x4 *)(bufc + a_base + dz * IY * IX * 4);
+                b_cur[0] = *(const f32x4 *)(wcur);
+                b_cur[1] = *(const f32x4 *)(wcur + 256);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t + 1 < 9) {
+                        const int dy = (t + 1) / 3, dx = (t + 1) - dy * 3;
+                        a_nxt = *(const f32x4 *)(bufc + a_base + ((dz * IY + dy) * IX + dx) * 4);
+                        b_nxt[0] = *(const f32x4 *)(wcur + (t + 1) * 512);
+                        b_nxt[1] = *(const f32x4 *)(wcur + (t + 1) * 512 + 256);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf)
+                            acc[0][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nf][j], a_cur[j], acc[0][nf], 0, 0, 0);
+                    a_cur = a_nxt; b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+                }
+                __syncthreads();  // retires the step's DMAs (vmcnt(0)); the other weight slot / brick buffer may be read now
+                wslot ^= 1;
+            }
+            buf ^= 1;
+        }
+        ConvArgs q = p;
+        q.lx = 5; q.ly = 1; q.lz = 1;
+        conv_epilogue<1, 2>(acc, q, cur.n, cur.oz0, cur.oy0, cur.ox0, (int)blockIdx.y * 64, red, /*sync_before_red=*/false);
+        cur = nxt_tile;
+    }
+}
+
 // MI355_WINOGRAD: 0 = direct kernels only, 1 = F(2,3) along y, 2 (default) = F(2x2,3x3) over (z, y)
 static int winograd_mode() {
     static int v = -1;
@@ -1264,6 +1429,41 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
         if (MF == 2) { *kernel_name = "conv3_f32_mfma_pipe_kernel<2, 1>"; return launch_pipe<2, 1>(pa, grid, lds_bytes, s); }
         *kernel_name = "conv3_f32_mfma_pipe_kernel<1, 1>";
         return launch_pipe<1, 1>(pa, grid, lds_bytes, s);
+    }
+    if (st == 2 && w.cc == 8 && w.nf == 2 && !c.head_out) {
+        static int s2dma = -1;
+        if (s2dma < 0) { const char *e = getenv("MI355_S2_DMA"); s2dma = (e && e[0] == '0') ? 0 : 1; }
+        ConvArgs b = a;
+        b.lz = 1; b.ly = 1; b.lx = 5;
+        b.tiles_x = ceil_div(b.Wo, 32); b.tiles_y = ceil_div(b.Ho, 2); b.tiles_z = ceil_div(b.Do, 2);
+        b.IX = S2_IX; b.IY = S2_IY; b.IZ = S2_IZ;
+        b.div_tiles_per_n = make_fastdiv(b.tiles_x * b.tiles_y * b.tiles_z);
+        b.div_tiles_x = make_fastdiv(b.tiles_x);
+        b.div_tiles_y = make_fastdiv(b.tiles_y);
+        b.div_IX = make_fastdiv(b.IX);
+        b.div_IY = make_fastdiv(b.IY);
+        const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
+        const int gy = w.cout / 64;
+        // persistent workgroups need a few tiles each, and the fixed 2x2x32 tile wastes lanes on narrow volumes
+        if (s2dma && tiles * gy >= 1024 && tiles < (1l << 30) && b.Wo >= 24 &&
+            (long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) < (1l << 31)) {
+            static float *zeros = nullptr;
+            if (!zeros) {
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_s2dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_BYTES));
+                MI355_HIP(hipMalloc(&zeros, 256));
+                MI355_HIP(hipMemset(zeros, 0, 256));
+            }
+            Wino2Args wa;
+            wa.c = b; wa.total_tiles = (int)tiles; wa.zeros = zeros;
+            int gx = 256 / gy;
+            gx = gx < 8 ? 8 : (gx / 8) * 8;
+            const int need = (int)((tiles + 7) / 8) * 8;
+            if (gx > need) gx = need;
+            *kernel_name = "conv3_f32_s2dma_kernel";
+            hipLaunchKernelGGL(conv3_f32_s2dma_kernel, dim3(gx, gy), dim3(256), S2_LDS_BYTES, s, wa);
+            MI355_HIP(hipGetLastError());
+            return MI355_OK;
+        }
     }
     int MF = (st == 1) ? 4 : 1;
     fill_geometry(a, st, 128 * MF);

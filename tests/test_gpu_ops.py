@@ -33,7 +33,9 @@ CONV_CASES = [
     (1, 16, 16, 32, 4, 64, 1, 0),      # stem with two cout blocks
     (3, 9, 7, 131, 40, 96, 2, 1),      # stride 2: odd input dims, ragged x tiles, 5 chunks of 8, 3 cout blocks
     (1, 64, 64, 64, 32, 64, 2, 1),     # stride 2 at a network-like size
-    (1, 64, 64, 64, 32, 64, 1, 1),     # >= 512 workgroups: the Winograd F(2,3)-along-y kernel, two cout blocks
+    (2, 64, 64, 128, 32, 64, 2, 1),    # stride 2, >= 1024 tiles: the persistent LDS-DMA stride-2 kernel
+    (3, 50, 62, 90, 16, 128, 2, 0),    # the same kernel: ragged in z, y, x (odd input dims), 2 chunks, two cout blocks, batch
+    (1, 64, 64, 64, 32, 64, 1, 1),     # >= 512 workgroups: the Winograd kernel (F(2x2,3x3) by default), two cout blocks
     (3, 30, 37, 70, 48, 32, 1, 0),     # Winograd kernel: ragged in z, y (odd: half-used row pair) and x, 3 chunks, batch
 ]
 
