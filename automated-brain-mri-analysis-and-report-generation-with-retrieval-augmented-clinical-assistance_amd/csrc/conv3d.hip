@@ -961,17 +961,25 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
 // (8 per tap: 4 channel pairs x 2 cout fragments); the VALU work left is the DMA address arithmetic.
 // Step = (chunk, dz): 72 MFMAs per wave; the barrier that ends it retires the step's DMAs (vmcnt(0)) before anybody
 // reads what they fetched.
-constexpr int S2_IX = 65, S2_IY = 5, S2_IZ = 5, S2_BV = S2_IX * S2_IY * S2_IZ;   // 1625 brick voxels, 2 quads each
-constexpr int S2_RANGES = 28, S2_RSTRIDE = 59;                                     // DMA ranges [59r, 59r + 64) per quad plane
-constexpr int S2_PAD = S2_RANGES * S2_RSTRIDE + 5 - S2_BV;                         // slots written past the last plane
-constexpr int S2_BUF_FLOATS = (2 * S2_BV + S2_PAD) * 4;
-constexpr int S2_WSLOT_FLOATS = 9 * 2 * 256;                                       // one dz plane: 9 taps x 2 cout fragments
-constexpr size_t S2_LDS_BYTES = (size_t)(2 * S2_BUF_FLOATS + 2 * S2_WSLOT_FLOATS + 4 * 64 * 2) * sizeof(float);
+// Tile: 2 x 2 x 32 outputs (TXL = 5, brick 5 x 5 x 65) or 2 x 4 x 16 (TXL = 4, brick 5 x 9 x 33) for narrow volumes.
+template <int TXL>
+struct S2Geom {
+    static constexpr int TX = 1 << TXL, TY = 64 >> TXL;                           // a wave = one z plane half: 32 voxels
+    static constexpr int IX = 2 * TX + 1, IY = 2 * TY + 1, IZ = 5, BV = IX * IY * IZ;  // brick voxels, 2 quads each
+    static constexpr int RANGES = 28, RSTRIDE = (BV - 64 + 26) / 27;              // DMA ranges [RSTRIDE*r, +64) per quad plane
+    static constexpr int PAD = 27 * RSTRIDE + 64 - BV;                            // slots written past the last plane
+    static constexpr int BUF_FLOATS = (2 * BV + PAD) * 4;
+    static constexpr int WSLOT_FLOATS = 9 * 2 * 256;                              // one dz plane: 9 taps x 2 cout fragments
+    static constexpr size_t LDS_BYTES = (size_t)(2 * BUF_FLOATS + 2 * WSLOT_FLOATS + 4 * 64 * 2) * sizeof(float);
+};
 
+template <int TXL>
 __global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvArgs &p = pa.c;
-    constexpr int IX = S2_IX, IY = S2_IY, BV = S2_BV;
+    typedef S2Geom<TXL> GM;
+    constexpr int IX = GM::IX, IY = GM::IY, BV = GM::BV;
+    constexpr int S2_BUF_FLOATS = GM::BUF_FLOATS, S2_WSLOT_FLOATS = GM::WSLOT_FLOATS, S2_RSTRIDE = GM::RSTRIDE;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -997,7 +1005,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
         const int tile_x = tt - tzy * p.tiles_x;
         const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
         const int tile_y = tzy - tile_z * p.tiles_y;
-        tc.oz0 = tile_z << 1; tc.oy0 = tile_y << 1; tc.ox0 = tile_x << 5;  // tile is fixed: 2 x 2 x 32 outputs
+        tc.oz0 = tile_z << 1; tc.oy0 = tile_y * GM::TY; tc.ox0 = tile_x << TXL;
         return tc;
     };
 
@@ -1047,8 +1055,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
         }
     };
 
-    // wave w = output (z, y) = (w >> 1, w & 1) of the tile, lane = x; floats: input voxel (2z, 2y, 2x) at tap 0, quad `half`
-    const int a_base = half * BV * 4 + (((wave >> 1) * 2 * IY + (wave & 1) * 2) * IX + 2 * l31) * 4;
+    // wave w = z plane w >> 1, y rows (w & 1) * TY/2 ..; lane = (y row, x); floats: input voxel (2z, 2y, 2x) at tap 0, quad `half`
+    const int ay = (wave & 1) * (GM::TY / 2) + (l31 >> TXL), ax = l31 & (GM::TX - 1);
+    const int a_base = half * BV * 4 + (((wave >> 1) * 2 * IY + ay * 2) * IX + 2 * ax) * 4;
 
     TileCoord cur = decode(tile);
 #pragma unroll
@@ -1109,7 +1118,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
             buf ^= 1;
         }
         ConvArgs q = p;
-        q.lx = 5; q.ly = 1; q.lz = 1;
+        q.lx = TXL; q.ly = 6 - TXL; q.lz = 1;  // voxel v = wave * 32 + lane: x = v & (TX-1), y = (v >> TXL) & (TY-1), z = v >> 6
         conv_epilogue<1, 2>(acc, q, cur.n, cur.oz0, cur.oy0, cur.ox0, (int)blockIdx.y * 64, red, /*sync_before_red=*/false);
         cur = nxt_tile;
     }
@@ -1434,9 +1443,11 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
         static int s2dma = -1;
         if (s2dma < 0) { const char *e = getenv("MI355_S2_DMA"); s2dma = (e && e[0] == '0') ? 0 : 1; }
         ConvArgs b = a;
-        b.lz = 1; b.ly = 1; b.lx = 5;
-        b.tiles_x = ceil_div(b.Wo, 32); b.tiles_y = ceil_div(b.Ho, 2); b.tiles_z = ceil_div(b.Do, 2);
-        b.IX = S2_IX; b.IY = S2_IY; b.IZ = S2_IZ;
+        const int txl = b.Wo >= 24 ? 5 : 4;  // 2 x 2 x 32 tiles, or 2 x 4 x 16 on narrow volumes
+        const int TX = 1 << txl, TY = 64 >> txl;
+        b.lz = 1; b.ly = 6 - txl; b.lx = txl;
+        b.tiles_x = ceil_div(b.Wo, TX); b.tiles_y = ceil_div(b.Ho, TY); b.tiles_z = ceil_div(b.Do, 2);
+        b.IX = 2 * TX + 1; b.IY = 2 * TY + 1; b.IZ = 5;
         b.div_tiles_per_n = make_fastdiv(b.tiles_x * b.tiles_y * b.tiles_z);
         b.div_tiles_x = make_fastdiv(b.tiles_x);
         b.div_tiles_y = make_fastdiv(b.tiles_y);
@@ -1444,12 +1455,13 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
         b.div_IY = make_fastdiv(b.IY);
         const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
         const int gy = w.cout / 64;
-        // persistent workgroups need a few tiles each, and the fixed 2x2x32 tile wastes lanes on narrow volumes
-        if (s2dma && tiles * gy >= 1024 && tiles < (1l << 30) && b.Wo >= 24 &&
+        // persistent workgroups need a few tiles each, and the fixed tiles waste lanes on very small volumes
+        if (s2dma && tiles * gy >= 768 && tiles < (1l << 30) && b.Wo >= 12 && b.Ho >= 3 &&
             (long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) < (1l << 31)) {
             static float *zeros = nullptr;
             if (!zeros) {
-                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_s2dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_LDS_BYTES));
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_s2dma_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2Geom<5>::LDS_BYTES));
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_s2dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2Geom<4>::LDS_BYTES));
                 MI355_HIP(hipMalloc(&zeros, 256));
                 MI355_HIP(hipMemset(zeros, 0, 256));
             }
@@ -1459,8 +1471,9 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
             gx = gx < 8 ? 8 : (gx / 8) * 8;
             const int need = (int)((tiles + 7) / 8) * 8;
             if (gx > need) gx = need;
-            *kernel_name = "conv3_f32_s2dma_kernel";
-            hipLaunchKernelGGL(conv3_f32_s2dma_kernel, dim3(gx, gy), dim3(256), S2_LDS_BYTES, s, wa);
+            *kernel_name = txl == 5 ? "conv3_f32_s2dma_kernel<5>" : "conv3_f32_s2dma_kernel<4>";
+            if (txl == 5) hipLaunchKernelGGL(conv3_f32_s2dma_kernel<5>, dim3(gx, gy), dim3(256), S2Geom<5>::LDS_BYTES, s, wa);
+            else hipLaunchKernelGGL(conv3_f32_s2dma_kernel<4>, dim3(gx, gy), dim3(256), S2Geom<4>::LDS_BYTES, s, wa);
             MI355_HIP(hipGetLastError());
             return MI355_OK;
         }
