@@ -41,6 +41,7 @@ struct ConvArgsH {
     float *head_out;
     int head_ncls;
     int plane_bytes;  // brickvox * 16
+    const void *zeros;  // >= 32 B of zeros in global memory (stride-2 DMA kernel: source of out-of-volume pieces)
 };
 
 // Epilogue shared by both kernels (C/D map of the 32x32 MFMA: col = lane&31 = voxel,
@@ -483,6 +484,159 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
     }
 }
 
+// ------------------------------------------------------------------ stride 2: persistent LDS-DMA kernel
+// fp16 twin of conv3_f32_s2dma_kernel (conv3d.hip): one persistent workgroup per CU, the 16-channel halo brick
+// (2 planes of 16-B pieces) double-buffered and filled by LDS-DMA, the weights of one dz plane (9 taps x 64 couts =
+// 18 KiB) per step through a two-slot LDS ring shared by the four waves.  Per tap a wave reads one voxel fragment and
+// two weight fragments from LDS and issues two MFMAs: 3 KiB per 64 matrix cycles per wave - the kernel is bound by the
+// LDS (192 B/clk asked of 128), which is still three times what per-wave weight streaming through the L1 delivered.
+template <int TXL>
+struct S2GeomH {
+    static constexpr int TX = 1 << TXL, TY = 64 >> TXL;
+    static constexpr int IX = 2 * TX + 1, IY = 2 * TY + 1, IZ = 5, BV = IX * IY * IZ;
+    static constexpr int RSTRIDE = (BV - 64 + 26) / 27;      // 28 DMA ranges [RSTRIDE*r, +64) per plane
+    static constexpr int PAD = 27 * RSTRIDE + 64 - BV;
+    static constexpr int BUF_BYTES = (2 * BV + PAD) * 16;
+    static constexpr int WSLOT_BYTES = 9 * 2 * 1024;
+    static constexpr size_t LDS_BYTES = (size_t)2 * BUF_BYTES + 2 * WSLOT_BYTES + 4 * 64 * 2 * sizeof(float);
+};
+
+template <int TXL>
+__global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(ConvArgsH p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    typedef S2GeomH<TXL> GM;
+    constexpr int IX = GM::IX, IY = GM::IY, BV = GM::BV;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    char *wring = lds_raw + 2 * GM::BUF_BYTES;
+    float *red = (float *)(wring + 2 * GM::WSLOT_BYTES);
+
+    const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x - xcd + 7) >> 3;
+    const int q8 = p.total_tiles >> 3, r8 = p.total_tiles & 7;
+    const int lo = xcd * q8 + (xcd < r8 ? xcd : r8);
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + li;
+    if (tile >= hi) return;
+
+    struct TileCoord { int n, oz0, oy0, ox0; };
+    auto decode = [&](int t) {
+        TileCoord tc;
+        tc.n = (int)fdiv((uint32_t)t, p.div_tiles_per_n);
+        const int tt = t - tc.n * (int)p.div_tiles_per_n.d;
+        const int tzy = (int)fdiv((uint32_t)tt, p.div_tiles_x);
+        const int tile_x = tt - tzy * p.tiles_x;
+        const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
+        const int tile_y = tzy - tile_z * p.tiles_y;
+        tc.oz0 = tile_z << 1; tc.oy0 = tile_y * GM::TY; tc.ox0 = tile_x << TXL;
+        return tc;
+    };
+
+    unsigned dma_pk[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        int bv = (wave + 4 * k) * GM::RSTRIDE + lane;
+        const int over = bv >= BV ? 1 : 0;
+        bv -= over * BV;
+        const int rr = bv / IX, bx = bv - rr * IX;
+        const int rz = rr / IY, ry = rr - rz * IY;
+        dma_pk[k] = (unsigned)(rz | (ry << 4) | (bx << 8) | (over << 16));
+    }
+    auto dma_brick = [&](const TileCoord &tc, int ch, int k, char *buf) {
+        const int rng = wave + 4 * k;
+        const int cglob = ch * 16;
+        const half_t *src; int Csrc, coff;
+        if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
+        else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
+        src += ((((size_t)tc.n * p.Di + (2 * tc.oz0 - 1)) * p.Hi + (2 * tc.oy0 - 1)) * p.Wi + (2 * tc.ox0 - 1)) * (long)Csrc + coff;
+        const unsigned pk = dma_pk[k];
+        const int rz = pk & 15, ry = (pk >> 4) & 15, bx = (pk >> 8) & 255, over = pk >> 16;
+        const bool in_vol = ((unsigned)(2 * tc.oz0 - 1 + rz) < (unsigned)p.Di) && ((unsigned)(2 * tc.oy0 - 1 + ry) < (unsigned)p.Hi) &&
+                            ((unsigned)(2 * tc.ox0 - 1 + bx) < (unsigned)p.Wi);
+        const int voff = ((rz * p.Hi + ry) * p.Wi + bx) * Csrc + over * 8;  // halfs
+        const half_t *g0 = in_vol ? src + voff : (const half_t *)p.zeros;
+        const half_t *g1 = (in_vol && over == 0) ? src + voff : (const half_t *)p.zeros;  // plane 1's overrun lanes fill padding
+        asm volatile("" : "+v"(g0), "+v"(g1));
+        char *dst = buf + rng * GM::RSTRIDE * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g0,
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g1,
+                                         (__attribute__((address_space(3))) void *)(dst + BV * 16 - 16), 16, 16, 0);
+    };
+    const char *wblk = (const char *)(p.wp + (size_t)blockIdx.y * p.nchunks * (27 * 2 * 512));
+    auto dma_weights = [&](int ch, int dz, char *slot) {
+        const char *wsrc = wblk + ((size_t)ch * 27 + dz * 9) * 2048 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int kib = wave + 4 * i;
+            if (kib < 18)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + kib * 1024),
+                                                 (__attribute__((address_space(3))) void *)(slot + kib * 1024), 16, 0, 0);
+        }
+    };
+
+    const int ay = (wave & 1) * (GM::TY / 2) + (l31 >> TXL), ax = l31 & (GM::TX - 1);
+    const int a_base = half * BV * 16 + (((wave >> 1) * 2 * IY + ay * 2) * IX + 2 * ax) * 16;  // bytes
+    const int co_blk = (int)blockIdx.y * 64;
+
+    TileCoord cur = decode(tile);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) dma_brick(cur, 0, k, lds_raw);
+    dma_weights(0, 0, wring);
+    __syncthreads();
+
+    int buf = 0, wslot = 0;
+    for (; tile < hi; tile += nl) {
+        f32x16 acc[1][2];
+        acc_init_bias<1, 2>(acc, p.bias, co_blk, half);
+        const int ntile = tile + nl;
+        const TileCoord nxt_tile = ntile < hi ? decode(ntile) : cur;
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const bool last_ch = ch == p.nchunks - 1;
+            const bool have_next = !last_ch || ntile < hi;
+            const TileCoord nxt = last_ch ? nxt_tile : cur;
+            const int nch = last_ch ? 0 : ch + 1;
+            const char *bufc = lds_raw + buf * GM::BUF_BYTES;
+            char *bufn = lds_raw + (buf ^ 1) * GM::BUF_BYTES;
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                if (dz < 2) dma_weights(ch, dz + 1, wring + (wslot ^ 1) * GM::WSLOT_BYTES);
+                else if (have_next) dma_weights(nch, 0, wring + (wslot ^ 1) * GM::WSLOT_BYTES);
+                if (have_next) {
+                    if (dz == 0) { dma_brick(nxt, nch, 0, bufn); dma_brick(nxt, nch, 1, bufn); dma_brick(nxt, nch, 2, bufn); }
+                    else if (dz == 1) { dma_brick(nxt, nch, 3, bufn); dma_brick(nxt, nch, 4, bufn); }
+                    else { dma_brick(nxt, nch, 5, bufn); dma_brick(nxt, nch, 6, bufn); }
+                }
+                const char *wcur = wring + wslot * GM::WSLOT_BYTES + lane * 16;
+                f16x8 a_cur, a_nxt, b_cur[2], b_nxt[2];
+                a_cur = *(const f16x8 *)(bufc + a_base + dz * IY * IX * 16);
+                b_cur[0] = *(const f16x8 *)(wcur);
+                b_cur[1] = *(const f16x8 *)(wcur + 1024);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t + 1 < 9) {
+                        const int dy = (t + 1) / 3, dx = (t + 1) - dy * 3;
+                        a_nxt = *(const f16x8 *)(bufc + a_base + ((dz * IY + dy) * IX + dx) * 16);
+                        b_nxt[0] = *(const f16x8 *)(wcur + (t + 1) * 2048);
+                        b_nxt[1] = *(const f16x8 *)(wcur + (t + 1) * 2048 + 1024);
+                    }
+#pragma unroll
+                    for (int nf = 0; nf < 2; ++nf)
+                        acc[0][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_cur[nf], a_cur, acc[0][nf], 0, 0, 0);
+                    a_cur = a_nxt; b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+                }
+                __syncthreads();  // retires the step's DMAs (vmcnt(0)); the other weight slot / brick buffer may be read now
+                wslot ^= 1;
+            }
+            buf ^= 1;
+        }
+        ConvArgsH q = p;
+        q.lx = TXL; q.ly = 6 - TXL; q.lz = 1;  // voxel v = wave * 32 + lane: x = v & (TX-1), y = (v >> TXL) & (TY-1), z = v >> 6
+        conv_epilogue_f16<1, 2>(acc, q, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red);
+        if (p.stats) __syncthreads();  // the statistics scratch is reused by the next tile
+        cur = nxt_tile;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 // Packed layout (halfs): [cout_block][chunk][tap][nf][lane 0..63][j 0..7] with
 //   cout = (cout_block*NF + nf)*32 + (lane&31),  cin = chunk*16 + (lane>>5)*8 + j.
@@ -587,6 +741,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
     a.nchunks = w.cin_pad / 16;
     a.act = c.act; a.slope = c.slope;
     a.total_tiles = 0;
+    a.zeros = nullptr;
     const int gy = w.cout / (32 * w.nf);
     static size_t attr[8] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
     if (st == 1 && use_pipe_h()) {
@@ -620,6 +775,44 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1>, a, grid, lds_bytes, s, &attr[0]);
         if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1>, a, grid, lds_bytes, s, &attr[1]);
         return launch_h(conv3_f16_mfma_pipe_kernel<2, 2>, a, grid, lds_bytes, s, &attr[2]);
+    }
+    if (st == 2 && w.nf == 2 && !c.head_out) {
+        static int s2dma = -1;
+        if (s2dma < 0) { const char *e = getenv("MI355_S2_DMA"); s2dma = (e && e[0] == '0') ? 0 : 1; }
+        ConvArgsH b = a;
+        const int txl = b.Wo >= 24 ? 5 : 4;  // 2 x 2 x 32 tiles, or 2 x 4 x 16 on narrow volumes
+        const int TX = 1 << txl, TY = 64 >> txl;
+        b.lz = 1; b.ly = 6 - txl; b.lx = txl;
+        b.tiles_x = ceil_div(b.Wo, TX); b.tiles_y = ceil_div(b.Ho, TY); b.tiles_z = ceil_div(b.Do, 2);
+        b.IX = 2 * TX + 1; b.IY = 2 * TY + 1; b.IZ = 5;
+        b.div_tiles_per_n = make_fastdiv(b.tiles_x * b.tiles_y * b.tiles_z);
+        b.div_tiles_x = make_fastdiv(b.tiles_x);
+        b.div_tiles_y = make_fastdiv(b.tiles_y);
+        b.div_IX = make_fastdiv(b.IX);
+        b.div_IY = make_fastdiv(b.IY);
+        const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
+        const int gy2 = w.cout / 64;
+        if (s2dma && tiles * gy2 >= 768 && tiles < (1l << 30) && b.Wo >= 12 && b.Ho >= 3 &&
+            (long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) < (1l << 31)) {
+            static void *zeros = nullptr;
+            if (!zeros) {
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f16_s2dma_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2GeomH<5>::LDS_BYTES));
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f16_s2dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2GeomH<4>::LDS_BYTES));
+                MI355_HIP(hipMalloc(&zeros, 256));
+                MI355_HIP(hipMemset(zeros, 0, 256));
+            }
+            b.zeros = zeros;
+            b.total_tiles = (int)tiles;
+            int gx = 256 / gy2;
+            gx = gx < 8 ? 8 : (gx / 8) * 8;
+            const int need = (int)((tiles + 7) / 8) * 8;
+            if (gx > need) gx = need;
+            if (kernel_name) *kernel_name = txl == 5 ? "conv3_f16_s2dma_kernel<5>" : "conv3_f16_s2dma_kernel<4>";
+            if (txl == 5) hipLaunchKernelGGL(conv3_f16_s2dma_kernel<5>, dim3(gx, gy2), dim3(256), S2GeomH<5>::LDS_BYTES, s, b);
+            else hipLaunchKernelGGL(conv3_f16_s2dma_kernel<4>, dim3(gx, gy2), dim3(256), S2GeomH<4>::LDS_BYTES, s, b);
+            MI355_HIP(hipGetLastError());
+            return MI355_OK;
+        }
     }
     const int MF = (st == 1) ? 2 : 1;
     fill_geometry_h(a, st, 128 * MF);

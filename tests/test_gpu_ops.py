@@ -157,6 +157,9 @@ F16_CONV_CASES = [
     (1, 16, 16, 32, 4, 64, 1, 0),
     (3, 9, 7, 131, 48, 96, 2, 1),    # stride 2: odd input dims, ragged x tiles, 3 chunks of 16, 3 cout blocks
     (1, 64, 64, 64, 32, 64, 2, 1),   # stride 2 at a network-like size
+    (2, 64, 64, 128, 32, 64, 2, 1),  # stride 2, >= 768 tiles: the persistent LDS-DMA stride-2 kernel
+    (3, 50, 62, 90, 16, 128, 2, 0),  # the same kernel: ragged in z, y, x (odd input dims), two cout blocks, batch
+    (8, 32, 30, 32, 128, 256, 2, 1), # the same kernel on a narrow volume (Wo = 16): 2 x 4 x 16 tiles, 8 chunks
 ]
 
 
