@@ -912,6 +912,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier
             __syncthreads();  // retires this chunk's DMA (vmcnt(0)) and orders it before the next chunk's ds_reads
             buf ^= 1;
         }
@@ -1112,6 +1113,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
                             acc[0][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nf][j], a_cur[j], acc[0][nf], 0, 0, 0);
                     a_cur = a_nxt; b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier
                 __syncthreads();  // retires the step's DMAs (vmcnt(0)); the other weight slot / brick buffer may be read now
                 wslot ^= 1;
             }

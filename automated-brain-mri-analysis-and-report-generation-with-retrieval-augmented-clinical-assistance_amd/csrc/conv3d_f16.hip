@@ -624,6 +624,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(ConvArgsH p) {
                         acc[0][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_cur[nf], a_cur, acc[0][nf], 0, 0, 0);
                     a_cur = a_nxt; b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier
                 __syncthreads();  // retires the step's DMAs (vmcnt(0)); the other weight slot / brick buffer may be read now
                 wslot ^= 1;
             }
