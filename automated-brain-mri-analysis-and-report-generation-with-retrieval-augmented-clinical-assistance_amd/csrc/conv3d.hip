@@ -97,6 +97,39 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
         }
         return;
     }
+    if (!p.stats) {
+        // plain path: bias, LeakyReLU as max(x, slope * x) (slope 1 = none), wide stores; packed f32 math - on a SIMD whose
+        // matrix pipe waits for this epilogue every VALU instruction counts (tools/coissue_probe.hip)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const float slope = p.act == ACT_LRELU ? p.slope : 1.0f;
+        const f32x2 slope2 = {slope, slope};
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int v = (wave * MF + mf) * 32 + l31;
+            const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
+            const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
+            float *orow = p.out + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + 4 * half;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bias = *(const f32x4 *)(p.bias + co_blk + nf * 32 + 8 * g + 4 * half);
+                    f32x4 val;
+#pragma unroll
+                    for (int k = 0; k < 4; k += 2) {
+                        f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
+                        const f32x2 b2 = {bias[k], bias[k + 1]};
+                        f32x2 y;
+                        asm("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b2));
+                        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
+                        val[k] = fmaxf(x[0], y[0]);
+                        val[k + 1] = fmaxf(x[1], y[1]);
+                    }
+                    if (ok) *(f32x4 *)(orow + nf * 32 + 8 * g) = val;
+                }
+        }
+        return;
+    }
     float s1[NF][16], s2[NF][16];
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
@@ -119,13 +152,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
                     float x = acc[mf][nf][4 * g + k] + bias[k];
                     if (p.act == ACT_LRELU) x = x > 0.f ? x : x * p.slope;
                     val[k] = x;
-                    if (p.stats && ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
+                    if (ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
                 }
                 if (ok) *(f32x4 *)(orow + nf * 32 + 8 * g) = val;
             }
         }
     }
-    if (p.stats) {
+    {
         if (sync_before_red) __syncthreads();
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
