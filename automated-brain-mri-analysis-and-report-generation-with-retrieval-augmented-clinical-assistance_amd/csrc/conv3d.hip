@@ -42,6 +42,11 @@ struct ConvArgs {
     const float *head_w, *head_b;  // fused 1x1x1 head (see ConvCall)
     float *head_out;
     int head_ncls;
+    // split-K (simple kernel, small launches): blockIdx.z = slice of the channel chunks; raw partial sums go to `partial`
+    int ksplit;
+    float *partial;
+    const float *zero_bias;
+    long out_elems;
 };
 
 // Shared epilogue.  The MFMAs are issued as D = W x X (weights are the A operand, voxels the B operand),
@@ -231,7 +236,9 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
 
     const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * G * NF * 256) + lane * 4;
 
-    for (int ch = 0; ch < p.nchunks; ++ch) {
+    const int ks = (int)blockIdx.z;
+    const int ch_begin = p.ksplit > 1 ? ks * p.nchunks / p.ksplit : 0, ch_end = p.ksplit > 1 ? (ks + 1) * p.nchunks / p.ksplit : p.nchunks;
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
         // ---- stage the CC-channel input halo brick (zero outside the volume); Q lanes share one voxel,
         //      i.e. CC*4 contiguous bytes per voxel (whole 64-B half lines for CC = 16)
         const int cglob = ch * CC;
@@ -317,7 +324,34 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
         __syncthreads();  // brick is overwritten by the next chunk
     }
 
+    if (p.ksplit > 1) {  // raw partial sums of this channel slice; bias / activation happen in splitk_finish_kernel
+        ConvArgs q = p;
+        q.out = p.partial + (size_t)ks * p.out_elems;
+        q.bias = p.zero_bias; q.act = ACT_NONE; q.stats = nullptr; q.head_out = nullptr;
+        conv_epilogue<MF, NF>(acc, q, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32, lds, /*sync_before_red=*/false);
+        return;
+    }
     conv_epilogue<MF, NF>(acc, p, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32, lds, /*sync_before_red=*/false);
+}
+
+// out = act(sum_s partial[s] + bias[c]): the slices are added in slice order, so the result does not depend on scheduling
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float *partial, int S, long total4, int cout4, const float *bias,
+                                                            int act, float slope, float *out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    f32x4 v = *(const f32x4 *)(partial + i * 4);
+    for (int s2 = 1; s2 < S; ++s2) {
+        const f32x4 t = *(const f32x4 *)(partial + ((long)s2 * total4 + i) * 4);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    const f32x4 b = *(const f32x4 *)(bias + (i % cout4) * 4);
+    const float sl = act == ACT_LRELU ? slope : 1.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x = v[k] + b[k];
+        v[k] = act == ACT_LRELU ? (x > 0.f ? x : x * sl) : x;
+    }
+    *(f32x4 *)(out + i * 4) = v;
 }
 
 
@@ -1379,6 +1413,7 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
     a.Cout = w.cout;
     a.nchunks = w.cin_pad / w.cc;
     a.act = c.act; a.slope = c.slope;
+    a.ksplit = 1; a.partial = nullptr; a.zero_bias = nullptr; a.out_elems = 0;
     if (w.wpw_dev) {
         // auto mode, large launches: Winograd F(2,3) along y on fixed 4x4x32 tiles, 32 couts per workgroup
         ConvArgs b = a;
@@ -1436,6 +1471,54 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
             if (w.nf == 2) { *kernel_name = "conv3_f32_mfma_kernel<1, 16, 4, 2>"; return launch_conv<1, 16, 4, 2>(b, grid, brick_bytes, s); }
             *kernel_name = "conv3_f32_mfma_kernel<1, 16, 4, 1>";
             return launch_conv<1, 16, 4, 1>(b, grid, brick_bytes, s);
+        }
+    }
+    {
+        // Small launches (deep levels: few voxels, hundreds of channels) leave most CUs idle and run one long serial chain
+        // of chunks per workgroup: split the channel chunks over blockIdx.z, write raw partial sums, add them in slice
+        // order in a finishing pass (deterministic).  Only without run-time statistics / fused head.
+        static int splitk = -1;
+        if (splitk < 0) { const char *e = getenv("MI355_SPLITK"); splitk = (e && e[0] == '0') ? 0 : 1; }
+        if (splitk && !c.stats && !c.head_out && w.cc == 8 && a.nchunks >= 8) {
+            ConvArgs b = a;
+            const int MFs = st == 1 ? 2 : 1;
+            fill_geometry(b, st, 128 * MFs);
+            const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
+            const int gy = w.cout / (32 * w.nf);
+            const long units = tiles * gy;
+            const size_t brick_bytes = (size_t)b.IX * b.IY * b.IZ * 8 * sizeof(float);
+            int S = (int)((512 + units - 1) / units);
+            if (S > a.nchunks / 4) S = a.nchunks / 4;
+            if (S > 8) S = 8;
+            if (units < 256 && S >= 2 && brick_bytes <= 80 * 1024 && w.cout <= 4096) {
+                static float *partial = nullptr, *zero_bias = nullptr;
+                static size_t partial_bytes = 0;
+                const long out_elems = (long)c.N * a.Do * a.Ho * a.Wo * w.cout;
+                const size_t need = (size_t)S * out_elems * sizeof(float);
+                if (!zero_bias) {
+                    MI355_HIP(hipMalloc(&zero_bias, 4096 * sizeof(float)));
+                    MI355_HIP(hipMemset(zero_bias, 0, 4096 * sizeof(float)));
+                }
+                if (need > partial_bytes) {
+                    if (partial) { MI355_HIP(hipStreamSynchronize(s)); (void)hipFree(partial); }
+                    MI355_HIP(hipMalloc(&partial, need));
+                    partial_bytes = need;
+                }
+                b.ksplit = S; b.partial = partial; b.zero_bias = zero_bias; b.out_elems = out_elems;
+                const size_t lds_bytes = brick_bytes < 4096 ? 4096 : brick_bytes;
+                dim3 grid((unsigned)tiles, gy, S);
+                int rc;
+                if (st == 1 && w.nf == 1) { *kernel_name = "conv3_f32_mfma_kernel<1, 8, 2, 1> split-K"; rc = launch_conv<1, 8, 2, 1>(b, grid, lds_bytes, s); }
+                else if (st == 1) { *kernel_name = "conv3_f32_mfma_kernel<1, 8, 2, 2> split-K"; rc = launch_conv<1, 8, 2, 2>(b, grid, lds_bytes, s); }
+                else if (w.nf == 1) { *kernel_name = "conv3_f32_mfma_kernel<2, 8, 1, 1> split-K"; rc = launch_conv<2, 8, 1, 1>(b, grid, lds_bytes, s); }
+                else { *kernel_name = "conv3_f32_mfma_kernel<2, 8, 1, 2> split-K"; rc = launch_conv<2, 8, 1, 2>(b, grid, lds_bytes, s); }
+                if (rc != MI355_OK) return rc;
+                const long total4 = out_elems / 4;
+                hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial, S, total4, w.cout / 4,
+                                   w.bias_dev, c.act, c.slope, c.out);
+                MI355_HIP(hipGetLastError());
+                return MI355_OK;
+            }
         }
     }
     if (w.pipe) {
