@@ -42,6 +42,10 @@ struct ConvArgsH {
     int head_ncls;
     int plane_bytes;  // brickvox * 16
     const void *zeros;  // >= 32 B of zeros in global memory (stride-2 DMA kernel: source of out-of-volume pieces)
+    // split-K (simple kernel, small launches): blockIdx.z = slice of the channel chunks; fp32 partial sums go to `partial`
+    int ksplit;
+    float *partial;
+    long out_elems;
 };
 
 // Epilogue shared by both kernels (C/D map of the 32x32 MFMA: col = lane&31 = voxel,
@@ -209,10 +213,21 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
         a_base[mf] = half * p.plane_bytes + ((z * STRIDE * IY + y * STRIDE) * IX + x * STRIDE) * 16;
     }
     f32x16 acc[MF][NF];
-    acc_init_bias<MF, NF>(acc, p.bias, (int)blockIdx.y * NF * 32, half);
+    const int ks = (int)blockIdx.z;
+    const int ch_begin = p.ksplit > 1 ? ks * p.nchunks / p.ksplit : 0, ch_end = p.ksplit > 1 ? (ks + 1) * p.nchunks / p.ksplit : p.nchunks;
+    if (ks == 0) {
+        acc_init_bias<MF, NF>(acc, p.bias, (int)blockIdx.y * NF * 32, half);  // the bias travels with slice 0
+    } else {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+    }
 
     const half_t *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512) + lane * 8;
-    for (int ch = 0; ch < p.nchunks; ++ch) {
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int cglob = ch * 16;
         const half_t *src; int Csrc, coff;
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
@@ -271,7 +286,42 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
         }
         __syncthreads();
     }
+    if (p.ksplit > 1) {
+        // raw fp32 partial sums of this channel slice, NDHWC like the output; activation / rounding in splitk_finish_f16_kernel
+        float *part = p.partial + (size_t)ks * p.out_elems;
+        const int co_blk = (int)blockIdx.y * NF * 32;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int v = (wave * MF + mf) * 32 + l31;
+            const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
+            if ((oz < p.Do) && (oy < p.Ho) && (ox < p.Wo)) {
+                float *orow = part + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + 4 * half;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *(f32x4 *)(orow + nf * 32 + 8 * g) = f32x4{acc[mf][nf][4 * g], acc[mf][nf][4 * g + 1], acc[mf][nf][4 * g + 2], acc[mf][nf][4 * g + 3]};
+            }
+        }
+        return;
+    }
     conv_epilogue_f16<MF, NF>(acc, p, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32, (float *)lds_raw);
+}
+
+// out = fp16(act(sum_s partial[s])), slices added in slice order (slice 0 carries the bias)
+__global__ __launch_bounds__(256) void splitk_finish_f16_kernel(const float *partial, int S, long total4, int act, float slope, half_t *out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    f32x4 v = *(const f32x4 *)(partial + i * 4);
+    for (int s2 = 1; s2 < S; ++s2) {
+        const f32x4 t = *(const f32x4 *)(partial + ((long)s2 * total4 + i) * 4);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    const float sl = act == ACT_LRELU ? slope : 1.0f;
+    f16x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (half_t)fmaxf(v[k], v[k] * sl);
+    *(f16x4 *)(out + i * 4) = o;
 }
 
 // ------------------------------------------------------------------ pipelined persistent kernel (stride 1)
@@ -743,8 +793,50 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
     a.act = c.act; a.slope = c.slope;
     a.total_tiles = 0;
     a.zeros = nullptr;
+    a.ksplit = 1; a.partial = nullptr; a.out_elems = 0;
     const int gy = w.cout / (32 * w.nf);
     static size_t attr[8] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+    {
+        // split-K for small launches (deep levels), as in conv3d.hip: fp32 partial sums, deterministic finishing pass
+        static int splitk = -1;
+        if (splitk < 0) { const char *e = getenv("MI355_SPLITK"); splitk = (e && e[0] == '0') ? 0 : 1; }
+        if (splitk && !c.stats && !c.head_out && a.nchunks >= 8) {
+            ConvArgsH b = a;
+            const int MFs = st == 1 ? 2 : 1;
+            fill_geometry_h(b, st, 128 * MFs);
+            const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
+            const long units = tiles * gy;
+            int S = (int)((512 + units - 1) / units);
+            if (S > a.nchunks / 4) S = a.nchunks / 4;
+            if (S > 8) S = 8;
+            size_t lds_bytes = (size_t)2 * b.plane_bytes;
+            if (lds_bytes < 4096) lds_bytes = 4096;
+            if (units < 256 && S >= 2 && lds_bytes <= 80 * 1024) {
+                static float *partial = nullptr;
+                static size_t partial_bytes = 0;
+                const long out_elems = (long)c.N * a.Do * a.Ho * a.Wo * w.cout;
+                const size_t need = (size_t)S * out_elems * sizeof(float);
+                if (need > partial_bytes) {
+                    if (partial) { MI355_HIP(hipStreamSynchronize(s)); (void)hipFree(partial); }
+                    MI355_HIP(hipMalloc(&partial, need));
+                    partial_bytes = need;
+                }
+                b.ksplit = S; b.partial = partial; b.out_elems = out_elems;
+                dim3 grid((unsigned)tiles, gy, S);
+                int rc;
+                static size_t attr_sk[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+                if (st == 1 && w.nf == 1) { if (kernel_name) *kernel_name = "conv3_f16_mfma_kernel<1, 2, 1> split-K"; rc = launch_h(conv3_f16_mfma_kernel<1, 2, 1>, b, grid, lds_bytes, s, &attr_sk[0]); }
+                else if (st == 1) { if (kernel_name) *kernel_name = "conv3_f16_mfma_kernel<1, 2, 2> split-K"; rc = launch_h(conv3_f16_mfma_kernel<1, 2, 2>, b, grid, lds_bytes, s, &attr_sk[1]); }
+                else if (w.nf == 1) { if (kernel_name) *kernel_name = "conv3_f16_mfma_kernel<2, 1, 1> split-K"; rc = launch_h(conv3_f16_mfma_kernel<2, 1, 1>, b, grid, lds_bytes, s, &attr_sk[2]); }
+                else { if (kernel_name) *kernel_name = "conv3_f16_mfma_kernel<2, 1, 2> split-K"; rc = launch_h(conv3_f16_mfma_kernel<2, 1, 2>, b, grid, lds_bytes, s, &attr_sk[3]); }
+                if (rc != MI355_OK) return rc;
+                const long total4 = out_elems / 4;
+                hipLaunchKernelGGL(splitk_finish_f16_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial, S, total4, c.act, c.slope, c.out);
+                MI355_HIP(hipGetLastError());
+                return MI355_OK;
+            }
+        }
+    }
     if (st == 1 && use_pipe_h()) {
         int MF = 4;
         fill_geometry_h(a, 1, 128 * MF);

@@ -163,6 +163,9 @@ F16_CONV_CASES = [
     (2, 64, 64, 128, 32, 64, 2, 1),  # stride 2, >= 768 tiles: the persistent LDS-DMA stride-2 kernel
     (3, 50, 62, 90, 16, 128, 2, 0),  # the same kernel: ragged in z, y, x (odd input dims), two cout blocks, batch
     (8, 32, 30, 32, 128, 256, 2, 1), # the same kernel on a narrow volume (Wo = 16): 2 x 4 x 16 tiles, 8 chunks
+    (8, 8, 8, 8, 320, 320, 1, 1),    # deep level: split-K over the 20 channel chunks + finishing pass
+    (8, 16, 16, 16, 256, 320, 2, 0), # deep stride-2 level: split-K, no activation
+    (2, 4, 4, 4, 320, 320, 1, 1),    # bottleneck-sized launch
 ]
 
 
