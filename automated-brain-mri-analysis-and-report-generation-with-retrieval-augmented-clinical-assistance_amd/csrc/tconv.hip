@@ -93,13 +93,12 @@ __global__ __launch_bounds__(256) void tconv2_f32_mfma_v2_kernel(const float *__
     const int nb = (int)blockIdx.y;
     const int G = Cin >> 3;
     const int m0 = (int)blockIdx.x * 128;
-    const float *xrow[4];
-#pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-        int v = m0 + mf * 32 + l31;
-        if (v >= M) v = M - 1;
-        xrow[mf] = in + (size_t)v * Cin + half * 4;
-    }
+    // The 128 input voxels are staged through LDS in 64-channel chunks with whole-line loads (16 consecutive lanes read
+    // the 256 contiguous bytes of one voxel); a fragment-shaped load straight from global would touch 64 lines per
+    // instruction for 16 B each, and the texture path, not the matrix pipe, would set the pace.  LDS image: planar
+    // [16-B channel quad][voxel], plane stride padded by one slot so that the staging writes are conflict-free too.
+    constexpr int XPLANE = 128 * 4 + 4;  // floats
+    __shared__ __attribute__((aligned(16))) float xs[16 * XPLANE];
     const float *wrow[2];
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) wrow[pp] = wp + ((size_t)((wave * 2 + pp) * nblk + nb) * G) * 256 + lane * 4;
@@ -110,42 +109,72 @@ __global__ __launch_bounds__(256) void tconv2_f32_mfma_v2_kernel(const float *__
         for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[pp][mf][r] = 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += 64) {
+        const int cq = (Cin - c0 < 64 ? Cin - c0 : 64) >> 2;  // channel quads in this chunk (Cin % 8 == 0)
+        if (c0) __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            const int i = k2 * 256 + tid, v = i >> 4, q = i & 15;
+            int vg = m0 + v;
+            if (vg >= M) vg = M - 1;
+            if (q < cq) *(f32x4 *)(xs + q * XPLANE + v * 4) = *(const f32x4 *)(in + (size_t)vg * Cin + c0 + q * 4);
+        }
+        __syncthreads();
+        const int gn = cq >> 1;
 #pragma unroll 2
-    for (int g = 0; g < G; ++g) {
-        f32x4 x[4], wv[2];
+        for (int g = 0; g < gn; ++g) {
+            f32x4 x[4], wv[2];
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) x[mf] = *(const f32x4 *)(xrow[mf] + g * 8);
+            for (int mf = 0; mf < 4; ++mf) x[mf] = *(const f32x4 *)(xs + (2 * g + half) * XPLANE + (mf * 32 + l31) * 4);
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) wv[pp] = *(const f32x4 *)(wrow[pp] + (size_t)g * 256);
+            for (int pp = 0; pp < 2; ++pp) wv[pp] = *(const f32x4 *)(wrow[pp] + (size_t)((c0 >> 3) + g) * 256);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
+                for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-                for (int mf = 0; mf < 4; ++mf)
-                    acc[pp][mf] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[pp][j], x[mf][j], acc[pp][mf], 0, 0, 0);
+                    for (int mf = 0; mf < 4; ++mf)
+                        acc[pp][mf] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[pp][j], x[mf][j], acc[pp][mf], 0, 0, 0);
+        }
     }
+    // Epilogue.  A lane holds one voxel and 16 couts, so a direct store instruction touches 32 different 128-B lines with
+    // 16-B pieces - 16 K line operations per workgroup through the texture path, as many cycles as the MFMAs take.  Each
+    // 32-voxel x 32-cout tile therefore goes through a 4-KB LDS transpose (XOR-swizzled 16-B pieces, conflict-free both
+    // ways) and is stored as whole lines: 8 lanes per voxel, 8 lines per instruction.
+    __shared__ __attribute__((aligned(16))) float tr[4][32 * 32];
+    float *mytr = tr[wave];
     const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf) {
         const int v = m0 + mf * 32 + l31;
-        if (v < M) {
-            const uint32_t q1 = fdiv((uint32_t)v, divW);
-            const int x = v - (int)q1 * W;
-            const uint32_t q2 = fdiv(q1, divH);
-            const int y = (int)q1 - (int)q2 * H;
-            const uint32_t n = fdiv(q2, divD);
-            const int z = (int)q2 - (int)n * D;
+        const int vc = v < M ? v : M - 1;
+        const uint32_t q1 = fdiv((uint32_t)vc, divW);
+        const int x = vc - (int)q1 * W;
+        const uint32_t q2 = fdiv(q1, divH);
+        const int y = (int)q1 - (int)q2 * H;
+        const uint32_t n = fdiv(q2, divD);
+        const int z = (int)q2 - (int)n * D;
+        // output voxel index of parity (0,0,0); -1 = voxel beyond the tensor
+        const long vox000 = v < M ? (((long)n * Do + 2 * z) * Ho + 2 * y) * Wo + 2 * x : -1;
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int pos = wave * 2 + pp;
-                const int pa = pos >> 2, pb = (pos >> 1) & 1, pc = pos & 1;
-                float *o = out + ((((size_t)n * Do + 2 * z + pa) * Ho + 2 * y + pb) * Wo + 2 * x + pc) * Cout + nb * 32 + 4 * half;
+        for (int pp = 0; pp < 2; ++pp) {
+            const int pos = wave * 2 + pp;
+            const int pa = pos >> 2, pb = (pos >> 1) & 1, pc = pos & 1;
+            const long padd = ((long)pa * Ho + pb) * Wo + pc;
+            // write: row = voxel l31, 16-B piece (2*g4 + half) at physical piece (piece ^ (row & 7))
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    f32x4 val = {acc[pp][mf][4 * g4], acc[pp][mf][4 * g4 + 1], acc[pp][mf][4 * g4 + 2], acc[pp][mf][4 * g4 + 3]};
-                    *(f32x4 *)(o + 8 * g4) = val;
-                }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 val = {acc[pp][mf][4 * g4], acc[pp][mf][4 * g4 + 1], acc[pp][mf][4 * g4 + 2], acc[pp][mf][4 * g4 + 3]};
+                *(f32x4 *)(mytr + l31 * 32 + (((2 * g4 + half) ^ (l31 & 7)) << 2)) = val;
+            }
+            // read back: lane = (row r, piece c); the row's output offset comes from the lane that owns the voxel
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3), c = lane & 7;
+                const f32x4 val = *(const f32x4 *)(mytr + r * 32 + ((c ^ (r & 7)) << 2));
+                const int lo = __shfl((int)(vox000 & 0xffffffff), r), hi = __shfl((int)(vox000 >> 32), r);
+                const long vo = ((long)hi << 32) | (unsigned)lo;
+                if (vo >= 0) *(f32x4 *)(out + (size_t)(vo + padd) * Cout + nb * 32 + c * 4) = val;
             }
         }
     }
