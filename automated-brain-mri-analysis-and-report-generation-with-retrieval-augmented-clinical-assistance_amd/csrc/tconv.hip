@@ -300,13 +300,14 @@ __global__ __launch_bounds__(256) void tconv2_f16_mfma_v2_kernel(const _Float16 
     const int nb = (int)blockIdx.y;
     const int G = Cin >> 4;
     const int m0 = (int)blockIdx.x * 128;
-    const _Float16 *xrow[4];
-#pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-        int v = m0 + mf * 32 + l31;
-        if (v >= M) v = M - 1;
-        xrow[mf] = in + (size_t)v * Cin + half * 8;
-    }
+    // As in the fp32 kernel: input staged through LDS in 64-channel chunks with whole-line loads (8 lanes read the 128
+    // contiguous bytes of a voxel), planar [16-B piece][voxel] image with a padded plane stride; output transposed through
+    // LDS so that a store instruction writes whole 128-B lines.  A wave's two parities differ in x only, so the rows
+    // (voxel, parity 2w) and (voxel, parity 2w+1) are adjacent in memory: one 128-B line = 2 x 32 couts.
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int XPLANE = 128 * 8 + 8;  // halfs
+    __shared__ __attribute__((aligned(16))) _Float16 xs[8 * XPLANE];
+    __shared__ __attribute__((aligned(16))) _Float16 tr[4][32 * 64];
     const _Float16 *wrow[2];
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) wrow[pp] = wp + ((size_t)((wave * 2 + pp) * nblk + nb) * G) * 512 + lane * 8;
@@ -317,42 +318,63 @@ __global__ __launch_bounds__(256) void tconv2_f16_mfma_v2_kernel(const _Float16 
         for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[pp][mf][r] = 0.f;
-#pragma unroll 2
-    for (int g = 0; g < G; ++g) {
-        f16x8 x[4], wv[2];
+    for (int c0 = 0; c0 < Cin; c0 += 64) {
+        const int cp = (Cin - c0 < 64 ? Cin - c0 : 64) >> 3;  // 16-B pieces (8 channels) in this chunk (Cin % 16 == 0)
+        if (c0) __syncthreads();
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) x[mf] = *(const f16x8 *)(xrow[mf] + g * 16);
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const int i = k2 * 256 + tid, v = i >> 3, q = i & 7;
+            int vg = m0 + v;
+            if (vg >= M) vg = M - 1;
+            if (q < cp) *(f32x4_t *)(xs + q * XPLANE + v * 8) = *(const f32x4_t *)(in + (size_t)vg * Cin + c0 + q * 8);
+        }
+        __syncthreads();
+        const int gn = cp >> 1;
+        for (int g = 0; g < gn; ++g) {
+            f16x8 x[4], wv[2];
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) wv[pp] = *(const f16x8 *)(wrow[pp] + (size_t)g * 512);
+            for (int mf = 0; mf < 4; ++mf) x[mf] = *(const f16x8 *)(xs + (2 * g + half) * XPLANE + (mf * 32 + l31) * 8);
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
+            for (int pp = 0; pp < 2; ++pp) wv[pp] = *(const f16x8 *)(wrow[pp] + (size_t)((c0 >> 4) + g) * 512);
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf)
-                acc[pp][mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[pp], x[mf], acc[pp][mf], 0, 0, 0);
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    acc[pp][mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[pp], x[mf], acc[pp][mf], 0, 0, 0);
+        }
     }
+    _Float16 *mytr = tr[wave];
     const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+    const int pa = wave >> 1, pb = wave & 1;  // parities 2w, 2w+1 = (pa, pb, 0) and (pa, pb, 1)
+    const long padd = ((long)pa * Ho + pb) * Wo;
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf) {
         const int v = m0 + mf * 32 + l31;
-        if (v < M) {
-            const uint32_t q1 = fdiv((uint32_t)v, divW);
-            const int x = v - (int)q1 * W;
-            const uint32_t q2 = fdiv(q1, divH);
-            const int y = (int)q1 - (int)q2 * H;
-            const uint32_t n = fdiv(q2, divD);
-            const int z = (int)q2 - (int)n * D;
+        const int vc = v < M ? v : M - 1;
+        const uint32_t q1 = fdiv((uint32_t)vc, divW);
+        const int x = vc - (int)q1 * W;
+        const uint32_t q2 = fdiv(q1, divH);
+        const int y = (int)q1 - (int)q2 * H;
+        const uint32_t n = fdiv(q2, divD);
+        const int z = (int)q2 - (int)n * D;
+        const long vox000 = v < M ? (((long)n * Do + 2 * z) * Ho + 2 * y) * Wo + 2 * x : -1;
+        // write: row = voxel l31 (128 B = 2 parities x 32 couts); 16-B piece pp*4 + g4 at physical piece (piece ^ (row & 7))
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int pos = wave * 2 + pp;
-                const int pa = pos >> 2, pb = (pos >> 1) & 1, pc = pos & 1;
-                _Float16 *o = out + ((((size_t)n * Do + 2 * z + pa) * Ho + 2 * y + pb) * Wo + 2 * x + pc) * Cout + nb * 32 + 4 * half;
+        for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    f16x4 hv = {(_Float16)acc[pp][mf][4 * g4], (_Float16)acc[pp][mf][4 * g4 + 1],
-                                (_Float16)acc[pp][mf][4 * g4 + 2], (_Float16)acc[pp][mf][4 * g4 + 3]};
-                    *(f16x4 *)(o + 8 * g4) = hv;
-                }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f16x4 hv = {(_Float16)acc[pp][mf][4 * g4], (_Float16)acc[pp][mf][4 * g4 + 1],
+                                  (_Float16)acc[pp][mf][4 * g4 + 2], (_Float16)acc[pp][mf][4 * g4 + 3]};
+                *(f16x4 *)(mytr + l31 * 64 + (((pp * 4 + g4) ^ (l31 & 7)) << 3) + half * 4) = hv;
             }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + (lane >> 3), c = lane & 7;
+            const f32x4_t val = *(const f32x4_t *)(mytr + r * 64 + ((c ^ (r & 7)) << 3));
+            const int lo = __shfl((int)(vox000 & 0xffffffff), r), hi = __shfl((int)(vox000 >> 32), r);
+            const long vo = ((long)hi << 32) | (unsigned)lo;
+            // piece c: parity (c >> 2), couts 8 * (c & 3) .. + 7 of this cout block
+            if (vo >= 0) *(f32x4_t *)(out + (size_t)(vo + padd + (c >> 2)) * Cout + nb * 32 + (c & 3) * 8) = val;
         }
     }
 }
