@@ -127,8 +127,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
                         f32x2 y;
                         asm("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b2));
                         asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
-                        val[k] = fmaxf(x[0], y[0]);
-                        val[k + 1] = fmaxf(x[1], y[1]);
+                        asm("v_max_f32 %0, %1, %2" : "=v"(val[k]) : "v"(x[0]), "v"(y[0]));      // bare max: fmaxf would add a
+                        asm("v_max_f32 %0, %1, %2" : "=v"(val[k + 1]) : "v"(x[1]), "v"(y[1]));  // canonicalising max per value
                     }
                     if (ok) *(f32x4 *)(orow + nf * 32 + 8 * g) = val;
                 }

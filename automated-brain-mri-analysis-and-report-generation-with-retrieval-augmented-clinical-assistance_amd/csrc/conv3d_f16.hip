@@ -125,11 +125,21 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
             for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    // max(x, slope * x) with packed multiplies and bare v_max_f32 (fmaxf adds a canonicalising max per
+                    // value; every VALU instruction of the epilogue is time the matrix pipe stands still)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 slope2 = {slope, slope};
                     f16x4 val;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float x = acc[mf][nf][4 * g + k];
-                        val[k] = (half_t)fmaxf(x, x * slope);
+                    for (int k = 0; k < 4; k += 2) {
+                        const f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
+                        f32x2 y;
+                        float m0, m1;
+                        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
+                        asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(x[0]), "v"(y[0]));
+                        asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(x[1]), "v"(y[1]));
+                        val[k] = (half_t)m0;
+                        val[k + 1] = (half_t)m1;
                     }
                     if (ok) *(f16x4 *)(orow + nf * 32 + 8 * g) = val;
                 }
