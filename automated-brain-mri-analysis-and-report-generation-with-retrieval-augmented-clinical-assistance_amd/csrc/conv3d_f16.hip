@@ -74,42 +74,52 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
     const bool lrelu = p.act == ACT_LRELU;
     const float slope = lrelu ? p.slope : 1.0f;  // max(x, 1*x) = x
     if (HEAD) {
-        // fused segmentation head (see conv3d.hip): the accumulators already hold conv + bias
+        // Fused segmentation head on the matrix cores.  logits[c][voxel] = sum_cout Wh[c][cout] * act[cout][voxel] is one
+        // more small GEMM, and the activation tile already sits in the accumulators in exactly the lane = voxel layout of
+        // an MFMA B operand: registers 0..7 and 8..15 of a lane are two K = 16 slices (K order = the lane's cout order,
+        // matched by the A operand built below).  The head weights stay fp32-accurate: Wh = hi + lo in fp16, two MFMAs
+        // each.  4 MFMAs per voxel fragment replace ~100 VALU instructions (FMAs + a cross-half shuffle per class).
         // (separate instantiation: carrying this path in the plain kernels costs them 220 B of spills)
-        constexpr int KMAX = 4;
         const int64_t Vo = (int64_t)p.Do * p.Ho * p.Wo;
+        // (launched with NF == 1 only: one 32-cout fragment per workgroup)
+        f16x8 wh[2][2];  // [K slice][hi / lo]: lane (class = l31, half) holds Wh[class][cout(r)] for r = 8*slice .. +7
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = sl * 8 + j;
+                const int co = co_blk + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float w = l31 < p.head_ncls ? p.head_w[l31 * p.Cout + co] : 0.f;
+                const half_t hi = (half_t)w;
+                wh[sl][0][j] = hi;
+                wh[sl][1][j] = (half_t)(w - (float)hi);
+            }
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
             const int v = (wave * MF + mf) * 32 + l31;
             const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
             const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
-            float part[KMAX] = {0.f, 0.f, 0.f, 0.f};
+            f16x8 act[2];
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
+            for (int r = 0; r < 16; ++r) {
+                const float y = acc[mf][0][r];
+                // the unfused path rounds the activation to fp16 before the head reads it: keep that rounding
+                act[r >> 3][r & 7] = (half_t)fmaxf(y, y * slope);
+            }
+            f32x16 d;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = co_blk + nf * 32 + 8 * g + 4 * half;
-                    f32x4 x;
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float y = acc[mf][nf][4 * g + k];
-                        // the unfused path rounds the activation to fp16 before the head reads it: keep that rounding
-                        x[k] = (float)(half_t)fmaxf(y, y * slope);
-                    }
-#pragma unroll
-                    for (int c = 0; c < KMAX; ++c)
-                        if (c < p.head_ncls) {
-                            const f32x4 hw = *(const f32x4 *)(p.head_w + c * p.Cout + co);
-                            part[c] += x[0] * hw[0] + x[1] * hw[1] + x[2] * hw[2] + x[3] * hw[3];
-                        }
-                }
-#pragma unroll
-            for (int c = 0; c < KMAX; ++c) part[c] += __shfl_xor(part[c], 32);
+            for (int sl = 0; sl < 2; ++sl) {
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sl][1], act[sl], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sl][0], act[sl], d, 0, 0, 0);
+            }
+            // D rows = classes: rows 0..3 are registers 0..3 of the half-0 lanes; column = this lane's voxel
             if (ok && half == 0) {
                 const int64_t vi = ((int64_t)oz * p.Ho + oy) * p.Wo + ox;
 #pragma unroll
-                for (int c = 0; c < KMAX; ++c)
-                    if (c < p.head_ncls) p.head_out[((int64_t)n * p.head_ncls + c) * Vo + vi] = part[c] + p.head_b[c];
+                for (int c = 0; c < 4; ++c)
+                    if (c < p.head_ncls) p.head_out[((int64_t)n * p.head_ncls + c) * Vo + vi] = d[c] + p.head_b[c];
             }
         }
         return;
