@@ -64,6 +64,7 @@ struct mi355_unet {
     bool prof_on = false;
     struct ProfRec { std::string name; double flops, bytes; hipEvent_t a, b; };
     std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;  // events are recycled: nothing is created inside a timed region after warm-up
 };
 
 namespace mi355 {
@@ -146,6 +147,8 @@ static void destroy(mi355_unet *net) {
     for (auto &t : net->tuh) tconv_weights_free_f16(&t);
     head_weights_free(&net->head);
     if (net->gauss_dev) (void)hipFree(net->gauss_dev);
+    for (auto &r : net->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : net->event_pool) (void)hipEventDestroy(e);
     delete net;
 }
 
@@ -211,7 +214,11 @@ struct ProfScope {
     ProfScope(mi355_unet *n, hipStream_t st, const std::string &name, double flops, double bytes) : net(n), s(st), on(n->prof_on), idx(0) {
         if (!on) return;
         mi355_unet::ProfRec r; r.name = name; r.flops = flops; r.bytes = bytes;
-        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+        auto take = [&](hipEvent_t *e) {
+            if (!net->event_pool.empty()) { *e = net->event_pool.back(); net->event_pool.pop_back(); return true; }
+            return hipEventCreate(e) == hipSuccess;
+        };
+        if (!take(&r.a) || !take(&r.b)) { on = false; return; }
         (void)hipEventRecord(r.a, s);
         idx = net->prof.size();
         net->prof.push_back(r);
@@ -633,6 +640,14 @@ extern "C" int mi355_unet_forward(mi355_unet_t net, const float *x_dev, int n, i
 extern "C" int mi355_profile_enable(mi355_unet_t net, int on) {
     MI355_REQUIRE(net, "null handle");
     net->prof_on = on != 0;
+    if (net->prof_on) {
+        // pre-create the events here, outside any timed region (a bench run records ~120 per step)
+        while (net->event_pool.size() < 4096) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            net->event_pool.push_back(e);
+        }
+    }
     return MI355_OK;
 }
 
@@ -644,8 +659,8 @@ extern "C" int mi355_profile_read(mi355_unet_t net, mi355_prof_entry *out, int m
     for (auto &r : net->prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        net->event_pool.push_back(r.a);
+        net->event_pool.push_back(r.b);
         int k = 0;
         for (; k < n; ++k) if (r.name == out[k].name) break;
         if (k == n) {
