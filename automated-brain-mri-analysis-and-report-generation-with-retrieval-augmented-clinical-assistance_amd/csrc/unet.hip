@@ -718,9 +718,17 @@ extern "C" int mi355_sw_predict(const mi355_unet_t *nets, int n_nets, const floa
     MI355_TRY(make_geom(*opts, Z, Y, X, &g));
     const int C = nets[0]->num_classes;
     const size_t ZYXp = (size_t)g.Zp[0] * g.Zp[1] * g.Zp[2];
-    float *agg = nullptr, *cnt = nullptr;
-    MI355_HIP(hipMalloc(&agg, ZYXp * C * sizeof(float)));
-    MI355_HIP(hipMalloc(&cnt, ZYXp * sizeof(float)));
+    // aggregation scratch: process-wide like the activation arena, grown on demand, never freed per call - a
+    // hipMalloc / synchronise / hipFree round trip per volume costs more than the small kernels of a step
+    static float *g_sw_scratch = nullptr;
+    static size_t g_sw_scratch_floats = 0;
+    const size_t need = ZYXp * (size_t)(C + 1);
+    if (need > g_sw_scratch_floats) {
+        if (g_sw_scratch) { MI355_HIP(hipDeviceSynchronize()); MI355_HIP(hipFree(g_sw_scratch)); g_sw_scratch = nullptr; g_sw_scratch_floats = 0; }
+        MI355_HIP(hipMalloc(&g_sw_scratch, need * sizeof(float)));
+        g_sw_scratch_floats = need;
+    }
+    float *agg = g_sw_scratch, *cnt = g_sw_scratch + ZYXp * C;
     int rc = MI355_OK;
     for (int f = 0; f < n_nets && rc == MI355_OK; ++f) {
         if (nets[f]->num_classes != C) { set_error("fold %d has %d classes, fold 0 has %d", f, nets[f]->num_classes, C); rc = MI355_ERR_INVALID; break; }
@@ -733,10 +741,7 @@ extern "C" int mi355_sw_predict(const mi355_unet_t *nets, int n_nets, const floa
     }
     // fold mean: np.mean(list_of_fp32_arrays, axis=0) = fp32 running sum in list order, one divide
     if (rc == MI355_OK && n_nets > 1) rc = scale_inplace(probs_dev, (int64_t)C * Z * Y * X, (float)n_nets, s);
-    hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(agg);
-    (void)hipFree(cnt);
-    if (rc == MI355_OK && e != hipSuccess) { set_error("stream sync failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
+    // asynchronous on `stream` like every other entry point that takes one: probs_dev is valid in stream order
     return rc;
 }
 

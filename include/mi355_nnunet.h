@@ -115,7 +115,9 @@ int mi355_unet_forward(mi355_unet_t net, const float *x_dev, int n, int d, int h
 /* Sliding-window prediction of one preprocessed volume.
  * vol_dev: [in_channels][Z][Y][X] fp32; probs_dev: [num_classes][Z][Y][X] fp32.
  * With n_nets > 1 the result is the arithmetic mean over the handles (folds), summed in
- * handle order (run_brats2021_inference_singlethread.py:128). */
+ * handle order (run_brats2021_inference_singlethread.py:128).
+ * Asynchronous on `stream`: the work is enqueued, probs_dev is valid in stream order (a device fault surfaces at the
+ * caller's next synchronisation, as with any HIP launch). */
 int mi355_sw_predict(const mi355_unet_t *nets, int n_nets, const float *vol_dev, int Z, int Y, int X,
                      const mi355_sw_opts *opts, float *probs_dev, void *stream);
 /* Host helper: the step table the predictor uses (nnU-Net v1 _compute_steps_for_sliding_window).
