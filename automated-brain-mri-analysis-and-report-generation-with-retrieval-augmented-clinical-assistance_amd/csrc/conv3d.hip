@@ -1,22 +1,25 @@
-// 3x3x3 convolution, NDHWC fp32, as an implicit GEMM on the gfx950 matrix cores.
+// 3x3x3 convolution, NDHWC fp32, on the gfx950 matrix cores.
 //
 // Replaces torch.nn.Conv3d(k=3, p=1, stride 1|2) inside ConvDropoutNormNonlin
 // (reference model_architecture/generic_UNet.py:56,69) - 99.7 % of the path's flops.
 //
-// GEMM view:  M = output voxels, N = Cout, K = 27 taps x Cin.
-//   * A operand (voxels x channels) comes from an LDS-staged input halo brick of CC channels:
-//     one 16-B ds_read_b128 per lane feeds FOUR v_mfma_f32_32x32x2_f32 (lane l holds channels
-//     g*8 + 4*(l>>5) + j, j = 0..3, of voxel l&31; MFMA j contracts the channel pair
-//     {g*8+j, g*8+4+j}).  Voxel stride in LDS is CC+4 floats so that the 16 lanes of a
-//     ds_read_b128 group fall on 16 distinct 16-B slots (conflict-free for x-consecutive lanes).
-//   * B operand (weights) is pre-permuted on the host into exactly that fragment order, 1 KiB per
-//     (tap, 8-channel group, 32-cout fragment); every wave streams it with one global_load_dwordx4
-//     per lane (L2 resident: all workgroups read the same few hundred KB).
-//   * f32-input MFMA is an exact k-ordered fmaf chain (no TF32 on gfx950), so results differ from
-//     the CPU reference only by summation order.
-// Epilogue: + bias, optional LeakyReLU, predicated NDHWC store (one 128-B line per voxel and
-// 32-cout fragment), optional per-(n, channel) sum / sum-of-squares for Instance/GroupNorm
-// (wave reduction -> LDS -> one fp64 atomic per channel per workgroup).
+// GEMM view: D[cout][voxel] = W x X with K = 27 taps x Cin.  The weights are the MFMA A operand, the voxels the B
+// operand, so a lane holds one voxel (column lane&31) and 16 couts of a 32x32 tile.
+//   * voxels come from an LDS image of the input halo brick, planar [16-B channel quad][brick voxel]: x-consecutive
+//     lanes read consecutive 16-B slots (conflict-free); one ds_read_b128 feeds four v_mfma_f32_32x32x2_f32 (lane l
+//     holds channels g*8 + 4*(l>>5) + j of voxel l&31; MFMA j contracts the channel pair {g*8+j, g*8+4+j});
+//   * weights are pre-permuted on the host into fragment order (1 KiB per (tap, 8-channel group, 32 couts));
+//   * f32-input MFMA is an exact k-ordered fmaf chain (no TF32 on gfx950).
+// Kernels in this file (dispatch: conv3d_mfma_f32 at the bottom; DESIGN.md section 5 has the measurements):
+//   conv3_f32_wino2_kernel      stride 1, large launches: Winograd F(2x2,3x3) over (z,y), LDS-DMA bricks   [default]
+//   conv3_f32_wino_kernel       stride 1, large launches: Winograd F(2,3) along y                   (MI355_WINOGRAD=1)
+//   conv3_f32_s2dma_kernel      stride 2, large launches: LDS-DMA bricks, weight planes through an LDS ring
+//   conv3_f32_mfma_pipe_kernel  stride 1, mid-size launches: persistent, register-staged double-buffered brick
+//   conv3_f32_mfma_kernel       everything else (one tile per workgroup, stride 1|2), also the split-K slices of the
+//                               deep levels (+ splitk_finish_kernel)
+//   conv3_direct_kernel         reference-order direct convolution (tests, odd channel counts)
+// Shared epilogue: + bias, LeakyReLU, predicated wide NDHWC stores; optionally per-(n, channel) sum / sum of squares
+// for Instance/GroupNorm (wave reduction -> LDS -> one fp64 atomic per channel and workgroup) or the fused 1x1x1 head.
 #include "kernels.h"
 
 #include <cstdlib>
