@@ -9,8 +9,11 @@
 //   * LDS image of the input brick is planar [8-channel half][brick voxel][16 B]: x-consecutive lanes
 //     read consecutive 16-B slots (conflict-free ds_read_b128), 32 B per voxel and chunk;
 //   * weights are packed on the host as [cout block][chunk][tap][nf][lane][8 halfs] (1 KiB fragments).
-// Two kernels: a simple one (one output tile per workgroup, stride 1|2) and the pipelined persistent
-// one for stride 1 (double-buffered brick staged while the 27 tap steps of the previous chunk run).
+// Kernels: conv3_f16_mfma_pipe_kernel (stride 1: persistent, double-buffered brick staged through a buffer descriptor
+// while the 27 tap steps of the previous chunk run; HEAD variant applies the 1x1x1 head with four extra MFMAs),
+// conv3_f16_s2dma_kernel (stride 2, large launches: LDS-DMA bricks + weight planes through LDS), and the simple
+// conv3_f16_mfma_kernel (one tile per workgroup, stride 1|2; also the split-K slices of the deep levels, finished by
+// splitk_finish_f16_kernel).
 #include "kernels.h"
 
 #include <cstdlib>
