@@ -201,6 +201,9 @@ def main(argv=None, script_dir=None):
     ap.add_argument("--folds", type=int, nargs="+", default=[0, 1, 2, 3, 4])
     ap.add_argument("--disable_tta", action="store_true")
     ap.add_argument("--step_size", type=float, default=0.5)
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
+                    help="f32 (default): what the reference computes on its CPU path; f16: fp16 storage / fp32 accumulation, "
+                         "the autocast setting the upstream trainer uses on a GPU (mixed_precision=True)")
     ap.add_argument("--label-format", dest="label_format", choices=("nnunet", "brats2025", "brats2021"), default="nnunet",
                     help="convention of the final <case>.nii.gz; 'nnunet' (default) is what the reference writes, the others "
                          "fold convert_labels_to_brats.py:34-55 into the export")
@@ -217,7 +220,7 @@ def main(argv=None, script_dir=None):
         print("\n" + "=" * 70 + f"\nMODEL {i}: {name.split('__')[0]}\n" + "=" * 70)
         outs.append(output_folder / f"temp_model{i}")
         run_model_single_threaded(base / name, args.input, outs[-1], tuple(args.folds), not args.disable_tta,
-                                  args.step_size)
+                                  args.step_size, dtype=args.dtype)
     print("\n" + "=" * 70 + "\nENSEMBLING MODEL PREDICTIONS\n" + "=" * 70)
     ensemble_label_files(outs[0], outs[1], output_folder, args.label_format)
     print("\n" + "=" * 70 + "\nSEGMENTATION COMPLETE!\n" + "=" * 70)

@@ -39,6 +39,7 @@ def main(argv=None):
     ap.add_argument("--save_npz", action="store_true")
     ap.add_argument("--disable_tta", action="store_true")
     ap.add_argument("--step_size", type=float, default=0.5)
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32", help="f16 = fp16 storage / fp32 accumulation (upstream autocast)")
     ap.add_argument("--ensemble", nargs=2, metavar=("FOLDER1", "FOLDER2"))
     ap.add_argument("--postprocess", metavar="FOLDER", help="apply_threshold_to_folder + label convention on label NIfTIs")
     ap.add_argument("--threshold", type=int, default=200)
@@ -52,7 +53,7 @@ def main(argv=None):
     if args.kaist:
         if not args.input_folder:
             ap.error("-i is required")
-        common = ["-t", args.task_name, "-m", args.model, "-p", args.plans_identifier, "--step_size", str(args.step_size),
+        common = ["-t", args.task_name, "-m", args.model, "-p", args.plans_identifier, "--step_size", str(args.step_size), "--dtype", args.dtype,
                   "-f", *[str(k) for k in args.folds]] + (["--disable_tta"] if args.disable_tta else [])
         raw = []
         for k, tr in enumerate((driver.MODEL1, driver.MODEL2), 1):
@@ -100,7 +101,7 @@ def main(argv=None):
     if not model_dir.exists():
         print(f"[ERROR] Model not found: {model_dir}")
         return 1
-    model = driver.LoadedModel(checkpoint.load_model_folder(model_dir, args.folds))
+    model = driver.LoadedModel(checkpoint.load_model_folder(model_dir, args.folds), dtype=args.dtype)
     for case, files in _cases(Path(args.input_folder)):
         driver.predict_case_single_threaded(model, files, str(out / f"{case}.nii.gz"), do_tta=not args.disable_tta,
                                             step_size=args.step_size, save_npz=args.save_npz)

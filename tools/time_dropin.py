@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--folds", type=int, default=1)
     ap.add_argument("--workdir", default="/tmp/dropin_timing")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "f16"))
     args = ap.parse_args()
     import brats_amd as amd
     work = Path(args.workdir)
@@ -43,7 +44,7 @@ def main():
     t_setup = time.perf_counter() - t0
     out = work / "results" / case
     cmd = [sys.executable, str(ROOT / "run_brats2021_inference_singlethread.py"), "--input", str(case_dir), "--output", str(out),
-           "--results_folder", str(results), "--folds", *[str(k) for k in range(args.folds)]]
+           "--results_folder", str(results), "--folds", *[str(k) for k in range(args.folds)], "--dtype", args.dtype]
     for trial in range(2):  # second run: page cache warm, as in a pipeline that processes many cases
         t1 = time.perf_counter()
         res = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True)
