@@ -144,3 +144,108 @@ extern "C" int mi355_cosine_topk(const float *vectors_dev, const float *query_de
     MI355_HIP(e);
     return k;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// crop_to_nonzero on the device (nnU-Net v1 cropping.crop_to_nonzero as trainer.preprocess_patient
+// runs it, run_brats2021_inference_singlethread.py:89): mask = OR_c(vol[c] != 0), scipy.ndimage.binary_fill_holes
+// (6-connectivity), bounding box.  Hole filling = flood fill of the background from the volume border: `state` is
+// 1 = tissue, 0 = background not yet reached, 2 = background connected to the border.  One sweep kernel per axis walks
+// every line of that axis forwards and backwards (a thread per line); sweeps repeat until none of them changes a
+// voxel - brain masks are nearly convex, so two or three rounds.  Integer work: bit-exact against scipy.
+__global__ void nonzero_state_kernel(const float *vol, int C, int64_t V, uint8_t *state) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+        bool nz = false;
+        for (int c = 0; c < C; ++c) nz |= vol[(int64_t)c * V + i] != 0.f;
+        state[i] = nz ? 1 : 0;
+    }
+}
+
+// axis 0 = z, 1 = y, 2 = x.  A line's end points are border voxels: background there is "outside" by definition.
+__global__ void fill_sweep_kernel(uint8_t *state, int Z, int Y, int X, int axis, int *changed) {
+    const int n1 = axis == 0 ? Y : Z, n2 = axis == 2 ? Y : X;          // the two other extents
+    const int line = blockIdx.x * blockDim.x + threadIdx.x;
+    if (line >= n1 * n2) return;
+    const int a = line / n2, b = line - a * n2;
+    const int len = axis == 0 ? Z : (axis == 1 ? Y : X);
+    int64_t base, stride;
+    if (axis == 0) { base = (int64_t)a * X + b; stride = (int64_t)Y * X; }                 // a = y, b = x
+    else if (axis == 1) { base = (int64_t)a * Y * X + b; stride = X; }                     // a = z, b = x
+    else { base = ((int64_t)a * Y + b) * X; stride = 1; }                                  // a = z, b = y
+    bool ch = false;
+    bool reach = true;  // beyond the border everything is outside
+    for (int i = 0; i < len; ++i) {
+        uint8_t &v = state[base + i * stride];
+        if (v == 1) reach = false;
+        else if (v == 2) reach = true;
+        else if (reach) { v = 2; ch = true; }
+    }
+    reach = true;
+    for (int i = len - 1; i >= 0; --i) {
+        uint8_t &v = state[base + i * stride];
+        if (v == 1) reach = false;
+        else if (v == 2) reach = true;
+        else if (reach) { v = 2; ch = true; }
+    }
+    if (ch) *changed = 1;
+}
+
+// mask = state != 2 (tissue or enclosed background); bbox[0..2] = min z,y,x, bbox[3..5] = max z,y,x over the mask
+__global__ void fill_finish_kernel(const uint8_t *state, uint8_t *mask, int Z, int Y, int X, int *bbox) {
+    const int64_t V = (int64_t)Z * Y * X;
+    int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool m = state[i] != 2;
+        mask[i] = m ? 1 : 0;
+        if (m) {
+            const int x = (int)(i % X), y = (int)((i / X) % Y), z = (int)(i / ((int64_t)X * Y));
+            lo[0] = min(lo[0], z); lo[1] = min(lo[1], y); lo[2] = min(lo[2], x);
+            hi[0] = max(hi[0], z); hi[1] = max(hi[1], y); hi[2] = max(hi[2], x);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int l = lo[k], h = hi[k];
+        for (int m = 1; m < 64; m <<= 1) { l = min(l, __shfl_xor(l, m)); h = max(h, __shfl_xor(h, m)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&bbox[k], l); atomicMax(&bbox[3 + k], h); }
+    }
+}
+
+extern "C" int mi355_crop_mask(const float *vol_dev, int C, int Z, int Y, int X, uint8_t *mask_dev, int32_t *bbox_host, void *stream) {
+    MI355_REQUIRE(vol_dev && mask_dev && bbox_host && C >= 1 && Z >= 1 && Y >= 1 && X >= 1, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t V = (int64_t)Z * Y * X;
+    uint8_t *state = nullptr;
+    int *flags = nullptr;  // [0] = changed, [1..6] = bbox
+    MI355_HIP(hipMalloc(&state, V));
+    MI355_HIP(hipMalloc(&flags, 8 * sizeof(int)));
+    int64_t blocks = (V + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(nonzero_state_kernel, dim3((unsigned)blocks), dim3(256), 0, s, vol_dev, C, V, state);
+    hipError_t e = hipGetLastError();
+    for (int round = 0; e == hipSuccess && round < 4096; ++round) {
+        (void)hipMemsetAsync(flags, 0, sizeof(int), s);
+        for (int axis = 0; axis < 3; ++axis) {
+            const int lines = axis == 0 ? Y * X : (axis == 1 ? Z * X : Z * Y);
+            hipLaunchKernelGGL(fill_sweep_kernel, dim3((unsigned)((lines + 127) / 128)), dim3(128), 0, s, state, Z, Y, X, axis, flags);
+        }
+        int changed = 0;
+        e = hipMemcpyAsync(&changed, flags, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (!changed) break;
+    }
+    int init[7] = {0, 1 << 30, 1 << 30, 1 << 30, -1, -1, -1};
+    if (e == hipSuccess) e = hipMemcpyAsync(flags, init, sizeof(init), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fill_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, state, mask_dev, Z, Y, X, flags + 1);
+        e = hipGetLastError();
+    }
+    int out[7];
+    if (e == hipSuccess) e = hipMemcpyAsync(out, flags, sizeof(out), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(state);
+    (void)hipFree(flags);
+    MI355_HIP(e);
+    MI355_REQUIRE(out[4] >= 0, "volume is all zeros: nothing to segment");
+    for (int k = 0; k < 3; ++k) { bbox_host[2 * k] = out[1 + k]; bbox_host[2 * k + 1] = out[4 + k] + 1; }  // [lo, hi) per axis
+    return MI355_OK;
+}

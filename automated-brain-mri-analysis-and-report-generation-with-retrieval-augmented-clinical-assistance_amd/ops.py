@@ -64,6 +64,22 @@ def prob_mean(a, b):
     return out
 
 
+def crop_mask(vol):
+    """Nonzero mask with holes filled and its bounding box, on the device (nnU-Net v1 ``crop_to_nonzero`` as the
+    reference's ``trainer.preprocess_patient`` runs it, driver :89).  vol: CUDA fp32 [C, Z, Y, X].
+    Returns (mask uint8 [Z, Y, X], bbox [[z_lo, z_hi], [y_lo, y_hi], [x_lo, x_hi]])."""
+    import torch
+    _require_cuda(vol, torch.float32, "vol")
+    if vol.dim() != 4:
+        raise ValueError("crop_mask expects [C, Z, Y, X]")
+    vol = vol.contiguous()
+    c, z, y, x = vol.shape
+    mask = torch.empty((z, y, x), dtype=torch.uint8, device=vol.device)
+    box = (C.c_int32 * 6)()
+    _lib.check(_lib.load().mi355_crop_mask(vol.data_ptr(), c, z, y, x, mask.data_ptr(), box, _stream(vol)), "mi355_crop_mask")
+    return mask, [[int(box[0]), int(box[1])], [int(box[2]), int(box[3])], [int(box[4]), int(box[5])]]
+
+
 def zscore_masked_(vol, mask):
     """In place: per channel x[m] = (x[m]-mean)/(std+1e-8), x[~m] = 0 (nonCT + use_mask_for_norm)."""
     import torch

@@ -4,8 +4,10 @@ Mirrors ``trainer.preprocess_patient`` as the reference driver calls it
 (run_brats2021_inference_singlethread.py:89) for the plans in ``data/temp_inference_output1``:
 crop to the nonzero bounding box (mask = OR over modalities, holes filled), identity transpose,
 no resampling (1 mm -> 1 mm), per-modality ``nonCT`` z-score with ``use_mask_for_norm=True``.
-The hole filling runs on the host (scipy flood fill); the masked statistics and the
-normalisation run on the GPU (``mi355_zscore_masked``).
+Everything after the file read runs on the GPU: nonzero mask, hole filling (border flood fill, bit-exact with
+scipy.ndimage.binary_fill_holes), bounding box (``mi355_crop_mask``), masked statistics and normalisation
+(``mi355_zscore_masked``).  ``crop_to_nonzero`` below is the host version of the same crop (kept for callers without
+a device tensor).
 """
 from __future__ import annotations
 
@@ -37,10 +39,13 @@ def preprocess_case(raw: np.ndarray, device="cuda") -> Tuple["object", Dict]:
     import torch
     from . import ops
     raw = np.asarray(raw, dtype=np.float32)
-    cropped, inside, bbox = crop_to_nonzero(raw)
-    data = torch.from_numpy(cropped).to(device)
-    mask = torch.from_numpy(inside.astype(np.uint8)).to(device)
+    vol = torch.from_numpy(np.ascontiguousarray(raw)).to(device)
+    full_mask, bbox = ops.crop_mask(vol)
+    sl = tuple(slice(lo, hi) for lo, hi in bbox)
+    data = vol[(slice(None),) + sl].contiguous()
+    mask = full_mask[sl].contiguous()
+    del vol, full_mask
     ops.zscore_masked_(data, mask)
     props = dict(crop_bbox=bbox, original_size_of_raw_data=tuple(int(v) for v in raw.shape[1:]),
-                 size_after_cropping=tuple(int(v) for v in cropped.shape[1:]))
+                 size_after_cropping=tuple(int(v) for v in data.shape[1:]))
     return data, props

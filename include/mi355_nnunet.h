@@ -157,6 +157,12 @@ int mi355_label_confusion(const uint8_t *pred_dev, const uint8_t *gt_dev, int64_
 int mi355_cosine_topk(const float *vectors_dev, const float *query_dev, int N, int D, int k, int32_t *idx_host,
                       float *scores_host, void *stream);
 
+/* crop_to_nonzero of trainer.preprocess_patient (run_brats2021_inference_singlethread.py:89; nnU-Net v1
+ * cropping.crop_to_nonzero): mask = OR_c(vol[c] != 0) with holes filled (scipy.ndimage.binary_fill_holes, 6-connectivity),
+ * bbox_host = {z_lo, z_hi, y_lo, y_hi, x_lo, x_hi} (hi exclusive).  vol_dev [C][Z][Y][X] fp32, mask_dev [Z][Y][X] uint8.
+ * Synchronous (returns the box). */
+int mi355_crop_mask(const float *vol_dev, int C, int Z, int Y, int X, uint8_t *mask_dev, int32_t *bbox_host, void *stream);
+
 /* Per-kernel timing with HIP events on the stream the kernels are launched on (bench.py's
  * roofline). flops / bytes are the ALGORITHMIC work of the recorded launches. */
 typedef struct {

@@ -211,3 +211,30 @@ def test_tconv_f16_matches_torch(amd, gpu, case):
     y = amd.ops.tconv3d_ndhwc(torch.from_numpy(x).to(gpu), wt.astype(np.float32)).float().cpu().numpy()
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("shape,seed", [((155, 240, 240), 1000), ((40, 56, 48), 5), ((33, 17, 29), 6)])
+def test_crop_mask_matches_scipy_fill_holes(amd, gpu, shape, seed):
+    """crop_to_nonzero on the device (nonzero mask, hole filling by border flood fill, bounding box): bit-exact against the
+    oracle's numpy + scipy.ndimage.binary_fill_holes restatement, on the bench volume (interior zero holes) and on volumes
+    with hand-made topology: enclosed cavities, a cavity open to the border through a tunnel, tissue touching the border."""
+    from oracle import tiler_ref
+    vol = amd.synthetic.make_volume(seed=seed, shape=shape).astype(np.float32)
+    rs = np.random.RandomState(seed)
+    z, y, x = shape
+    if z < 100:
+        vol[:, z // 2 - 3:z // 2 + 3, y // 2 - 4:y // 2 + 4, x // 2 - 5:x // 2 + 5] = 0          # enclosed cavity
+        vol[:, z // 3, y // 3, :x // 2] = 0                                                       # tunnel to the border ...
+        vol[:, z // 3 - 2:z // 3 + 2, y // 3 - 2:y // 3 + 2, x // 2 - 3:x // 2] = 0               # ... into a cavity: stays open
+        vol[:, 0, :5, :5] = rs.uniform(1, 2, size=(vol.shape[0], 5, 5))                            # tissue on the border
+    cropped, inside, bbox = tiler_ref.crop_to_nonzero(vol)
+    mask, box = amd.ops.crop_mask(torch.from_numpy(vol).to(gpu))
+    assert box == bbox
+    sl = tuple(slice(lo, hi) for lo, hi in bbox)
+    assert np.array_equal(mask.cpu().numpy()[sl].astype(bool), inside)
+    assert mask.cpu().numpy().sum() == inside.sum()                                                # nothing outside the box
+    # and the whole device preprocessing against the oracle's (crop + masked z-score)
+    data, props = amd.preprocessing.preprocess_case(vol)
+    want, wprops = tiler_ref.preprocess_case(vol)
+    assert props["crop_bbox"] == wprops["crop_bbox"] and tuple(data.shape) == want.shape
+    assert np.abs(data.cpu().numpy() - want).max() <= 2e-5
