@@ -25,7 +25,7 @@ EXPORTS = [
     "mi355_sw_finish", "mi355_regions_to_labels", "mi355_label_ensemble", "mi355_prob_mean",
     "mi355_zscore_masked", "mi355_conv3d_ndhwc", "mi355_tconv3d_ndhwc", "mi355_profile_enable",
     "mi355_profile_read", "mi355_conv3d_ndhwc_f16", "mi355_tconv3d_ndhwc_f16",
-    "mi355_label_remap", "mi355_label_confusion", "mi355_cosine_topk", "mi355_crop_mask",
+    "mi355_label_remap", "mi355_label_confusion", "mi355_cosine_topk", "mi355_crop_mask", "mi355_label_stats",
 ]
 
 
@@ -108,6 +108,7 @@ def load():
     lib.mi355_label_confusion.argtypes = [vp, vp, C.c_int64, C.c_int, C.POINTER(C.c_uint64), vp]
     lib.mi355_cosine_topk.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, c_int32_p, c_float_p, vp]
     lib.mi355_crop_mask.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, c_int32_p, vp]
+    lib.mi355_label_stats.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), vp]
     lib.mi355_profile_enable.argtypes = [vp, C.c_int]
     lib.mi355_profile_read.argtypes = [vp, C.POINTER(ProfEntry), C.c_int]
     _lib = lib

@@ -108,3 +108,42 @@ def metrics_from_confusion(cm, labels=(1, 2, 3)):
 def evaluate(pred, gt):
     """pred, gt: CUDA uint8 label maps in the BraTS convention -> metrics dict."""
     return metrics_from_confusion(confusion(pred, gt, 5))
+
+
+# ---- feature_extraction/utils.py:167-216 on the device --------------------------------------------------------
+REGION_LABELS = {"ncr": (1,), "ed": (2,), "et": (3, 4), "tc": (1, 3, 4), "wt": (1, 2, 3, 4)}  # utils.py:171-178
+
+
+def label_stats(seg, num_labels=5):
+    """seg: CUDA uint8 label map [d0, d1, d2] -> int64 array [num_labels, 10]: count, coordinate sums (3), minima (3),
+    maxima (3) per label value (one pass on the device)."""
+    import torch
+    if seg.dtype != torch.uint8 or not seg.is_cuda or seg.dim() != 3:
+        raise ValueError("label_stats: CUDA uint8 [d0, d1, d2] tensor expected")
+    seg = seg.contiguous()
+    out = np.zeros(num_labels * 10, dtype=np.int64)
+    stream = torch.cuda.current_stream(seg.device).cuda_stream
+    _lib.check(_lib.load().mi355_label_stats(seg.data_ptr(), seg.shape[0], seg.shape[1], seg.shape[2], num_labels,
+                                             out.ctypes.data_as(C.POINTER(C.c_int64)), stream), "mi355_label_stats")
+    return out.reshape(num_labels, 10)
+
+
+def tumor_region_features(seg, voxel_volume_cm3):
+    """Volumes, centroids and bounding boxes of the reference's tumour regions (utils.py:167-216: get_tumor_masks,
+    calculate_volume, get_centroid, get_bounding_box) from one device pass; axes named x, y, z in array order as there."""
+    st = label_stats(seg, 5)
+    out = {}
+    for name, labels in REGION_LABELS.items():
+        rows = st[list(labels)]
+        n = int(rows[:, 0].sum())
+        feat = {"volume_cm3": float(n * voxel_volume_cm3), "centroid": None, "bounding_box": None}
+        if n > 0:
+            present = rows[rows[:, 0] > 0]
+            sums = rows[:, 1:4].sum(axis=0)
+            lo, hi = present[:, 4:7].min(axis=0), present[:, 7:10].max(axis=0)
+            feat["centroid"] = {k: float(sums[i] / n) for i, k in enumerate("xyz")}
+            feat["bounding_box"] = {**{f"min_{k}": int(lo[i]) for i, k in enumerate("xyz")},
+                                    **{f"max_{k}": int(hi[i]) for i, k in enumerate("xyz")},
+                                    **{f"size_{k}": int(hi[i] - lo[i] + 1) for i, k in enumerate("xyz")}}
+        out[name] = feat
+    return out

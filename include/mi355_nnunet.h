@@ -163,6 +163,12 @@ int mi355_cosine_topk(const float *vectors_dev, const float *query_dev, int N, i
  * Synchronous (returns the box). */
 int mi355_crop_mask(const float *vol_dev, int C, int Z, int Y, int X, uint8_t *mask_dev, int32_t *bbox_host, void *stream);
 
+/* Per-label voxel statistics of a label map [d0][d1][d2] (feature_extraction/utils.py:167-216: the integers behind
+ * get_tumor_masks + calculate_volume + get_centroid + get_bounding_box).  stats_host[label * 10 + f], label < K <= 8:
+ * f = 0 count, 1..3 sum of the coordinates along axis 0..2, 4..6 minimum, 7..9 maximum coordinate (-1 / 2^40 when the
+ * label is absent; for label 0 only the count is filled).  Labels >= K are ignored.  Synchronous. */
+int mi355_label_stats(const uint8_t *seg_dev, int d0, int d1, int d2, int K, int64_t *stats_host, void *stream);
+
 /* Per-kernel timing with HIP events on the stream the kernels are launched on (bench.py's
  * roofline). flops / bytes are the ALGORITHMIC work of the recorded launches. */
 typedef struct {

@@ -75,3 +75,25 @@ class DummyVectorStoreRef:
         scores = self.vectors @ self.query_vector(query)
         top = np.argsort(scores)[::-1][:top_k]
         return [(self.documents[i], float(scores[i])) for i in top]
+
+
+def tumor_region_features(seg_data, voxel_volume_cm3):
+    """feature_extraction/utils.py:167-216 verbatim in behaviour: get_tumor_masks, calculate_volume, get_centroid,
+    get_bounding_box for the regions ncr, ed, et, tc, wt."""
+    seg = np.round(seg_data).astype(np.int32)
+    masks = {"ncr": seg == 1, "ed": seg == 2, "et": (seg == 3) | (seg == 4), "tc": (seg == 1) | (seg == 3) | (seg == 4),
+             "wt": seg > 0}
+    out = {}
+    for name, mask in masks.items():
+        feat = {"volume_cm3": float(mask.sum() * voxel_volume_cm3), "centroid": None, "bounding_box": None}
+        if mask.sum() > 0:
+            coords = np.array(np.where(mask)).T
+            c = coords.mean(axis=0)
+            feat["centroid"] = {"x": float(c[0]), "y": float(c[1]), "z": float(c[2])}
+            w = np.where(mask)
+            feat["bounding_box"] = {"min_x": int(w[0].min()), "min_y": int(w[1].min()), "min_z": int(w[2].min()),
+                                    "max_x": int(w[0].max()), "max_y": int(w[1].max()), "max_z": int(w[2].max()),
+                                    "size_x": int(w[0].max() - w[0].min() + 1), "size_y": int(w[1].max() - w[1].min() + 1),
+                                    "size_z": int(w[2].max() - w[2].min() + 1)}
+        out[name] = feat
+    return out

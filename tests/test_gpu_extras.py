@@ -89,3 +89,24 @@ def test_cosine_topk_large(amd, gpu):
     want = np.argsort(scores)[::-1][:5]
     assert [i for i, _ in got] == list(want)
     assert np.allclose([s for _, s in got], scores[want], atol=1e-5)
+
+
+@pytest.mark.parametrize("present", [(0.95, 0.02, 0.02, 0.01, 0.0), (0.9, 0.03, 0.03, 0.02, 0.02), (1.0, 0.0, 0.0, 0.0, 0.0), (0.98, 0.0, 0.02, 0.0, 0.0)])
+def test_tumor_region_features(amd, gpu, present):
+    """feature_extraction/utils.py:167-216 (volumes, centroids, bounding boxes of ncr / ed / et / tc / wt) from one device
+    pass: integers exact, centroids equal to numpy's float64 means (exact integer sums divided once)."""
+    rs = np.random.RandomState(11)
+    seg = _labels(rs, (240, 240, 155), present)          # nibabel axis order x, y, z; label 4 = BraTS-2021 ET
+    seg[:40] = 0                                          # make the boxes non-trivial
+    seg[:, 200:] = 0
+    got = amd.evaluate.tumor_region_features(torch.from_numpy(seg).to(gpu), 0.001)
+    want = extras_ref.tumor_region_features(seg, 0.001)
+    assert got.keys() == want.keys()
+    for name in want:
+        assert got[name]["volume_cm3"] == want[name]["volume_cm3"], name
+        assert got[name]["bounding_box"] == want[name]["bounding_box"], name
+        if want[name]["centroid"] is None:
+            assert got[name]["centroid"] is None
+        else:
+            for k in "xyz":
+                assert abs(got[name]["centroid"][k] - want[name]["centroid"][k]) <= 1e-9, (name, k)
