@@ -238,3 +238,43 @@ def test_crop_mask_matches_scipy_fill_holes(amd, gpu, shape, seed):
     want, wprops = tiler_ref.preprocess_case(vol)
     assert props["crop_bbox"] == wprops["crop_bbox"] and tuple(data.shape) == want.shape
     assert np.abs(data.cpu().numpy() - want).max() <= 2e-5
+
+
+_SWITCH_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import brats_amd as amd
+import torch.nn.functional as F
+rs = np.random.RandomState(3)
+worst = 0.0
+for (n, d, h, w, cin, cout, stride) in [(1, 64, 64, 64, 32, 64, 1), (2, 64, 64, 128, 32, 64, 2), (8, 8, 8, 8, 320, 320, 1)]:
+    x = rs.standard_normal((n, d, h, w, cin)).astype(np.float32)
+    wt = (rs.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(cin * 27)).astype(np.float32)
+    b = rs.standard_normal(cout).astype(np.float32)
+    ref = F.leaky_relu(F.conv3d(torch.from_numpy(x).permute(0, 4, 1, 2, 3), torch.from_numpy(wt), torch.from_numpy(b), stride=stride, padding=1), 0.01)
+    ref = ref.permute(0, 2, 3, 4, 1).numpy()
+    for dt in ("f32", "f16"):
+        if dt == "f32":
+            y = amd.ops.conv3d_ndhwc(torch.from_numpy(x).cuda(), wt, b, stride=stride, act=1, slope=0.01, impl="mfma").cpu().numpy()
+            tol = 2e-5
+        else:
+            y = amd.ops.conv3d_ndhwc(torch.from_numpy(x.astype(np.float16)).cuda(), wt, b, stride=stride, act=1, slope=0.01).float().cpu().numpy()
+            tol = 6e-3
+        err = float(np.abs(y - ref).max() / max(1.0, np.abs(ref).max()))
+        assert err <= tol, (dt, n, d, cin, cout, stride, err)
+        worst = max(worst, err)
+print("OK", worst)
+"""
+
+
+@pytest.mark.parametrize("env", [{"MI355_WINOGRAD": "0"}, {"MI355_WINOGRAD": "1"}, {"MI355_S2_DMA": "0", "MI355_SPLITK": "0"},
+                                 {"MI355_CONV_IMPL": "0"}])
+def test_conv_dispatch_switches_keep_working(amd, gpu, env):
+    """The A/B switches select the older kernels behind the same entry points (direct instead of Winograd, simple
+    instead of the stride-2 DMA / split-K kernels); they are read once per process, so each setting runs in a child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", _SWITCH_SCRIPT, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-1500:] + res.stderr[-1500:]
