@@ -230,3 +230,27 @@ def test_full_size_config2_properties_and_oracle_tiles(amd, gpu):
         d = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(1 / (1 + np.exp(-got[0]))),
                                         tiler_ref.regions_to_labels(1 / (1 + np.exp(-ref[0]))))
         assert d["mean"] >= 0.999
+
+
+def test_full_size_config3_f16_agrees_with_f32(amd, gpu):
+    """BASELINE.json configs[2] at full size (8-way mirror TTA, models A + B, label-round ensemble) in fp16 storage against
+    the fp32 path of the same library - the fp32 path is the one pinned to the CPU oracle tile by tile above, so this
+    carries the oracle's verdict to the full-size fp16 configuration: Dice of the ensembled label maps >= 0.999."""
+    raw = amd.synthetic.make_volume(seed=1001)
+    data, props = amd.preprocessing.preprocess_case(raw)
+    lo = [b[0] for b in props["crop_bbox"]]
+    kw = dict(patch_size=(128, 128, 128), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid")
+    segs = {}
+    for dtype in ("f32", "f16"):
+        per_model = []
+        for name, seed in (("A", 7), ("B", 8)):
+            sd, meta = amd.synthetic.make_model(name, seed=seed)
+            net = amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"], dtype=dtype)
+            probs = amd.predictor.predict_folds([net], data, **kw)
+            assert bool(torch.isfinite(probs).all())
+            per_model.append(amd.ops.regions_to_labels(probs, (1, 2, 3), lo, props["original_size_of_raw_data"]))
+            net.close()
+        segs[dtype] = amd.ops.label_ensemble(per_model[0], per_model[1]).cpu().numpy()
+    d = tiler_ref.brats_region_dice(segs["f16"], segs["f32"])
+    assert d["mean"] >= 0.999, d
+    assert set(np.unique(segs["f16"])) <= {0, 1, 2, 3}
