@@ -155,12 +155,14 @@ __global__ __launch_bounds__(256) void tconv2_f32_mfma_v2_kernel(const float *__
         const uint32_t n = fdiv(q2, divD);
         const int z = (int)q2 - (int)n * D;
         // output voxel index of parity (0,0,0); -1 = voxel beyond the tensor
-        const long vox000 = v < M ? (((long)n * Do + 2 * z) * Ho + 2 * y) * Wo + 2 * x : -1;
+        // element offset of the voxel's parity-(0,0,0) output row; -1 = voxel beyond the tensor (the row offset, not the
+        // voxel index, travels through the shuffles: no 64-bit multiply per store)
+        const long vox000 = v < M ? ((((long)n * Do + 2 * z) * Ho + 2 * y) * Wo + 2 * x) * Cout : -1;
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             const int pos = wave * 2 + pp;
             const int pa = pos >> 2, pb = (pos >> 1) & 1, pc = pos & 1;
-            const long padd = ((long)pa * Ho + pb) * Wo + pc;
+            const long padd = (((long)pa * Ho + pb) * Wo + pc) * Cout + nb * 32;
             // write: row = voxel l31, 16-B piece (2*g4 + half) at physical piece (piece ^ (row & 7))
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void tconv2_f32_mfma_v2_kernel(const float *__
                 const f32x4 val = *(const f32x4 *)(mytr + r * 32 + ((c ^ (r & 7)) << 2));
                 const int lo = __shfl((int)(vox000 & 0xffffffff), r), hi = __shfl((int)(vox000 >> 32), r);
                 const long vo = ((long)hi << 32) | (unsigned)lo;
-                if (vo >= 0) *(f32x4 *)(out + (size_t)(vo + padd) * Cout + nb * 32 + c * 4) = val;
+                if (vo >= 0) *(f32x4 *)(out + (vo + padd) + c * 4) = val;
             }
         }
     }
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void tconv2_f16_mfma_v2_kernel(const _Float16 
     _Float16 *mytr = tr[wave];
     const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
     const int pa = wave >> 1, pb = wave & 1;  // parities 2w, 2w+1 = (pa, pb, 0) and (pa, pb, 1)
-    const long padd = ((long)pa * Ho + pb) * Wo;
+    const long padd = (((long)pa * Ho + pb) * Wo) * Cout + nb * 32;  // elements
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf) {
         const int v = m0 + mf * 32 + l31;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void tconv2_f16_mfma_v2_kernel(const _Float16 
         const int y = (int)q1 - (int)q2 * H;
         const uint32_t n = fdiv(q2, divD);
         const int z = (int)q2 - (int)n * D;
-        const long vox000 = v < M ? (((long)n * Do + 2 * z) * Ho + 2 * y) * Wo + 2 * x : -1;
+        const long vox000 = v < M ? ((((long)n * Do + 2 * z) * Ho + 2 * y) * Wo + 2 * x) * Cout : -1;  // element offset of the row
         // write: row = voxel l31 (128 B = 2 parities x 32 couts); 16-B piece pp*4 + g4 at physical piece (piece ^ (row & 7))
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256) void tconv2_f16_mfma_v2_kernel(const _Float16 
             const int lo = __shfl((int)(vox000 & 0xffffffff), r), hi = __shfl((int)(vox000 >> 32), r);
             const long vo = ((long)hi << 32) | (unsigned)lo;
             // piece c: parity (c >> 2), couts 8 * (c & 3) .. + 7 of this cout block
-            if (vo >= 0) *(f32x4_t *)(out + (size_t)(vo + padd + (c >> 2)) * Cout + nb * 32 + (c & 3) * 8) = val;
+            if (vo >= 0) *(f32x4_t *)(out + (vo + padd) + (c >> 2) * Cout + (c & 3) * 8) = val;
         }
     }
 }
