@@ -1,19 +1,24 @@
 """Builds the gfx950 shared library (C ABI, no torch dependency) in-tree with hipcc.
 
 Each ``csrc/*.hip`` is compiled to an object file in parallel (``hipcc -c``), then linked into
-``lib/libmi355_nnunet.so``; objects are rebuilt only when their source or a header changed.
+``<repo>/lib/libmi355_nnunet.so`` (a short in-tree path: the package directory's prescribed name is ~100 characters
+long, and tools that list ``/proc/<pid>/maps`` truncate such lines); objects are rebuilt only when their source or a
+header changed.  Concurrent builders (torch.distributed ranks, parallel pipeline processes) serialise on an flock and
+link through a per-process temporary name, so nobody ever loads a half-written library.
 """
 from __future__ import annotations
 
+import fcntl
 import os
 import shutil
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
+from contextlib import contextmanager
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
-LIB_DIR = PKG_DIR / "lib"
+LIB_DIR = PKG_DIR.parent / "lib"
 OBJ_DIR = LIB_DIR / "obj"
 LIB_PATH = LIB_DIR / "libmi355_nnunet.so"
 SOURCES = ["conv3d.hip", "conv3d_f16.hip", "conv_stem.hip", "tconv.hip", "elementwise.hip", "extras.hip", "unet.hip"]
@@ -39,37 +44,55 @@ def needs_build() -> bool:
     return any(p.stat().st_mtime > t for p in deps)
 
 
+@contextmanager
+def _build_lock():
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    with open(LIB_DIR / ".build.lock", "w") as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
 def _compile(hipcc: str, src: Path, obj: Path, verbose: bool):
-    cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+    tmp = obj.with_suffix(f".o.{os.getpid()}.tmp")
+    cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        tmp.unlink(missing_ok=True)
         raise RuntimeError(f"hipcc failed on {src.name}:\n" + res.stdout + res.stderr)
+    os.replace(tmp, obj)
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """hipcc --offload-arch=gfx950: cross-compiles without a GPU."""
     if not force and not needs_build():
         return LIB_PATH
-    hipcc = find_hipcc()
-    OBJ_DIR.mkdir(parents=True, exist_ok=True)
-    hdr_time = max(p.stat().st_mtime for p in _headers())
-    jobs = []
-    for s in SOURCES:
-        src, obj = CSRC / s, OBJ_DIR / (s + ".o")
-        if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_time):
-            jobs.append((src, obj))
-    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
-        list(pool.map(lambda j: _compile(hipcc, j[0], j[1], verbose), jobs))
-    tmp = LIB_PATH.with_suffix(".so.tmp")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(OBJ_DIR / (s + ".o")) for s in SOURCES], "-o", str(tmp)]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
-    os.replace(tmp, LIB_PATH)
+    with _build_lock():
+        if not force and not needs_build():  # another process built it while we waited for the lock
+            return LIB_PATH
+        hipcc = find_hipcc()
+        OBJ_DIR.mkdir(parents=True, exist_ok=True)
+        hdr_time = max(p.stat().st_mtime for p in _headers())
+        jobs = []
+        for s in SOURCES:
+            src, obj = CSRC / s, OBJ_DIR / (s + ".o")
+            if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_time):
+                jobs.append((src, obj))
+        with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
+            list(pool.map(lambda j: _compile(hipcc, j[0], j[1], verbose), jobs))
+        tmp = LIB_PATH.with_suffix(f".so.{os.getpid()}.tmp")
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(OBJ_DIR / (s + ".o")) for s in SOURCES], "-o", str(tmp)]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            tmp.unlink(missing_ok=True)
+            raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
+        os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

@@ -12,6 +12,19 @@ namespace mi355 {
 
 void set_error(const char *fmt, ...);
 
+// One process per GPU: the library binds to the HIP device that is current at its first compute call (weights, the
+// activation arena, the scratch buffers below and the raised dynamic-LDS limits all live on / apply to that device)
+// and every later entry point fails with MI355_ERR_INVALID if another device is current.  Also fails with
+// MI355_ERR_NO_DEVICE when no gfx950 device is visible.
+int bind_device();
+
+// Process-wide scratch on the bound device, one buffer per slot, grown on demand (synchronise, free, allocate) under a
+// mutex and never freed per call; `zeroed` buffers are cleared when (re)allocated.  Work that uses a slot is ordered
+// by the caller's stream: one stream at a time per process ("Stream semantics").
+enum ScratchSlot { SCR_ARENA = 0, SCR_SW_AGG, SCR_SPLITK_F32, SCR_SPLITK_F16, SCR_ZEROS, SCR_ZERO_BIAS, SCR_SMALL, SCR_TOPK,
+                   SCR_CROP, SCR_ZSCORE, SCR_COUNT };
+int device_scratch(int slot, size_t bytes, void **out, bool zeroed = false);
+
 #define MI355_HIP(expr)                                                                    \
     do {                                                                                   \
         hipError_t e__ = (expr);                                                           \

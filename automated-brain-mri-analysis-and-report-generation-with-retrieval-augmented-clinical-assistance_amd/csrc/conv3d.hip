@@ -1437,13 +1437,14 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
             b.wp = w.wpw_dev;
             b.nchunks = w.cin_pad / 16;
             dim3 grid((unsigned)tiles, w.cout / 32);
-            static float *zeros = nullptr;
-            if (!zeros) {
+            static bool attr_set = false;
+            if (!attr_set) {
                 MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brick_bytes));
                 MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES));
-                MI355_HIP(hipMalloc(&zeros, 256));
-                MI355_HIP(hipMemset(zeros, 0, 256));
+                attr_set = true;
             }
+            float *zeros = nullptr;  // the zero page out-of-volume DMA pieces read
+            MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
             *kernel_name = w.wino2 ? "conv3_f32_wino2_kernel" : "conv3_f32_wino_kernel";
             if (w.wino2) {
                 Wino2Args wa;
@@ -1494,19 +1495,11 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
             if (S > a.nchunks / 4) S = a.nchunks / 4;
             if (S > 8) S = 8;
             if (units < 256 && S >= 2 && brick_bytes <= 80 * 1024 && w.cout <= 4096) {
-                static float *partial = nullptr, *zero_bias = nullptr;
-                static size_t partial_bytes = 0;
+                float *partial = nullptr, *zero_bias = nullptr;
                 const long out_elems = (long)c.N * a.Do * a.Ho * a.Wo * w.cout;
                 const size_t need = (size_t)S * out_elems * sizeof(float);
-                if (!zero_bias) {
-                    MI355_HIP(hipMalloc(&zero_bias, 4096 * sizeof(float)));
-                    MI355_HIP(hipMemset(zero_bias, 0, 4096 * sizeof(float)));
-                }
-                if (need > partial_bytes) {
-                    if (partial) { MI355_HIP(hipStreamSynchronize(s)); (void)hipFree(partial); }
-                    MI355_HIP(hipMalloc(&partial, need));
-                    partial_bytes = need;
-                }
+                MI355_TRY(device_scratch(SCR_ZERO_BIAS, 4096 * sizeof(float), (void **)&zero_bias, true));
+                MI355_TRY(device_scratch(SCR_SPLITK_F32, need, (void **)&partial));
                 b.ksplit = S; b.partial = partial; b.zero_bias = zero_bias; b.out_elems = out_elems;
                 const size_t lds_bytes = brick_bytes < 4096 ? 4096 : brick_bytes;
                 dim3 grid((unsigned)tiles, gy, S);
@@ -1579,13 +1572,14 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
         // persistent workgroups need a few tiles each, and the fixed tiles waste lanes on very small volumes
         if (s2dma && tiles * gy >= 768 && tiles < (1l << 30) && b.Wo >= 12 && b.Ho >= 3 &&
             (long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) < (1l << 31)) {
-            static float *zeros = nullptr;
-            if (!zeros) {
+            static bool attr_set = false;
+            if (!attr_set) {
                 MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_s2dma_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2Geom<5>::LDS_BYTES));
                 MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_s2dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2Geom<4>::LDS_BYTES));
-                MI355_HIP(hipMalloc(&zeros, 256));
-                MI355_HIP(hipMemset(zeros, 0, 256));
+                attr_set = true;
             }
+            float *zeros = nullptr;
+            MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
             Wino2Args wa;
             wa.c = b; wa.total_tiles = (int)tiles; wa.zeros = zeros;
             int gx = 256 / gy;

@@ -835,15 +835,10 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
             size_t lds_bytes = (size_t)2 * b.plane_bytes;
             if (lds_bytes < 4096) lds_bytes = 4096;
             if (units < 256 && S >= 2 && lds_bytes <= 80 * 1024) {
-                static float *partial = nullptr;
-                static size_t partial_bytes = 0;
+                float *partial = nullptr;
                 const long out_elems = (long)c.N * a.Do * a.Ho * a.Wo * w.cout;
                 const size_t need = (size_t)S * out_elems * sizeof(float);
-                if (need > partial_bytes) {
-                    if (partial) { MI355_HIP(hipStreamSynchronize(s)); (void)hipFree(partial); }
-                    MI355_HIP(hipMalloc(&partial, need));
-                    partial_bytes = need;
-                }
+                MI355_TRY(device_scratch(SCR_SPLITK_F16, need, (void **)&partial));
                 b.ksplit = S; b.partial = partial; b.out_elems = out_elems;
                 dim3 grid((unsigned)tiles, gy, S);
                 int rc;
@@ -910,13 +905,14 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         const int gy2 = w.cout / 64;
         if (s2dma && tiles * gy2 >= 768 && tiles < (1l << 30) && b.Wo >= 12 && b.Ho >= 3 &&
             (long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) < (1l << 31)) {
-            static void *zeros = nullptr;
-            if (!zeros) {
+            static bool attr_set = false;
+            if (!attr_set) {
                 MI355_HIP(hipFuncSetAttribute((const void *)conv3_f16_s2dma_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2GeomH<5>::LDS_BYTES));
                 MI355_HIP(hipFuncSetAttribute((const void *)conv3_f16_s2dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2GeomH<4>::LDS_BYTES));
-                MI355_HIP(hipMalloc(&zeros, 256));
-                MI355_HIP(hipMemset(zeros, 0, 256));
+                attr_set = true;
             }
+            void *zeros = nullptr;
+            MI355_TRY(device_scratch(SCR_ZEROS, 256, &zeros, true));
             b.zeros = zeros;
             b.total_tiles = (int)tiles;
             int gx = 256 / gy2;

@@ -458,6 +458,7 @@ int scale_inplace(float *x, int64_t n, float divisor, hipStream_t s) {
 // ------------------------------------------------------------------ export / ensemble / preprocess
 struct OrderList {
     int v[8];
+    int argmax;
 };
 
 __global__ void regions_to_labels_kernel(const float *probs, int C, int Z, int Y, int X, OrderList order,
@@ -468,9 +469,17 @@ __global__ void regions_to_labels_kernel(const float *probs, int C, int Z, int Y
         const int y = (int)((v / X) % Y);
         const int z = (int)(v / ((int64_t)X * Y));
         int lab = 0;
-        for (int k = 0; k < C; ++k)
-            if (probs[k * ZYX + v] > 0.5f)
-                lab = order.v[k];
+        if (order.argmax) {  // non-region trainers: seg = probs.argmax(0), first maximum wins like numpy
+            float best = probs[v];
+            for (int k = 1; k < C; ++k) {
+                const float p = probs[k * ZYX + v];
+                if (p > best) { best = p; lab = k; }
+            }
+        } else {
+            for (int k = 0; k < C; ++k)
+                if (probs[k * ZYX + v] > 0.5f)
+                    lab = order.v[k];
+        }
         labels[((int64_t)(z + bz) * FY + (y + by)) * FX + (x + bx)] = (uint8_t)lab;
     }
 }
@@ -491,8 +500,10 @@ __global__ void prob_mean_kernel(const float *a, const float *b, float *out, int
         out[i] = (a[i] + b[i]) / 2.0f;
 }
 
-// masked z-score: two launches per call (sums, then apply) over C channels.
-__global__ void masked_sums_kernel(const float *vol, const uint8_t *mask, int64_t V, double *sums) {
+// masked z-score: three launches per call (per-block partial sums, fixed-order finish, apply) over C channels.
+// No atomics: every block writes its (sum, sum of squares, count) to its own slot and the finish kernel adds the slots
+// in a fixed order, so the normalised volume is bit-reproducible run to run and identical on every rank.
+__global__ void masked_sums_kernel(const float *vol, const uint8_t *mask, int64_t V, double *partial) {
     const int c = blockIdx.y;
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x)
@@ -505,11 +516,23 @@ __global__ void masked_sums_kernel(const float *vol, const uint8_t *mask, int64_
         s2 += __shfl_down(s2, off);
         cnt += __shfl_down(cnt, off);
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(sums + c * 3 + 0, s1);
-        atomicAdd(sums + c * 3 + 1, s2);
-        atomicAdd(sums + c * 3 + 2, cnt);
+    __shared__ double w[4][3];
+    if ((threadIdx.x & 63) == 0) { w[threadIdx.x >> 6][0] = s1; w[threadIdx.x >> 6][1] = s2; w[threadIdx.x >> 6][2] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double *p = partial + ((size_t)c * gridDim.x + blockIdx.x) * 3;
+        p[threadIdx.x] = ((w[0][threadIdx.x] + w[1][threadIdx.x]) + w[2][threadIdx.x]) + w[3][threadIdx.x];
     }
+}
+
+// sums[c][k] = partial[c][0][k] + partial[c][1][k] + ... : one 64-lane wave per (c, k), lane-strided then a butterfly
+__global__ void masked_sums_finish_kernel(const double *partial, int nblocks, double *sums) {
+    const int c = blockIdx.x, k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (k >= 3) return;
+    double a = 0.0;
+    for (int b = lane; b < nblocks; b += 64) a += partial[((size_t)c * nblocks + b) * 3 + k];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (lane == 0) sums[c * 3 + k] = a;
 }
 
 __global__ void masked_zscore_kernel(float *vol, const uint8_t *mask, int64_t V, const double *sums) {
@@ -532,12 +555,14 @@ extern "C" int mi355_regions_to_labels(const float *probs_dev, int C, int Z, int
                                        const int32_t bbox_lo[3], const int32_t full[3], uint8_t *labels_dev,
                                        void *stream) {
     MI355_REQUIRE(C >= 1 && C <= 8, "regions_to_labels: %d channels", C);
+    MI355_TRY(bind_device());
     MI355_REQUIRE(bbox_lo[0] >= 0 && bbox_lo[1] >= 0 && bbox_lo[2] >= 0 && bbox_lo[0] + Z <= full[0] &&
                       bbox_lo[1] + Y <= full[1] && bbox_lo[2] + X <= full[2],
                   "regions_to_labels: crop box does not fit the full volume");
     hipStream_t s = (hipStream_t)stream;
     OrderList ol;
-    for (int i = 0; i < 8; ++i) ol.v[i] = i < C ? order[i] : 0;
+    for (int i = 0; i < 8; ++i) ol.v[i] = (order && i < C) ? order[i] : 0;
+    ol.argmax = order == nullptr;
     MI355_HIP(hipMemsetAsync(labels_dev, 0, (size_t)full[0] * full[1] * full[2], s));
     const int64_t ZYX = (int64_t)Z * Y * X;
     int64_t blocks = (ZYX + 255) / 256;
@@ -550,6 +575,7 @@ extern "C" int mi355_regions_to_labels(const float *probs_dev, int C, int Z, int
 
 extern "C" int mi355_label_ensemble(const uint8_t *a_dev, const uint8_t *b_dev, uint8_t *out_dev, int64_t n,
                                     void *stream) {
+    MI355_TRY(bind_device());
     int64_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
@@ -560,6 +586,7 @@ extern "C" int mi355_label_ensemble(const uint8_t *a_dev, const uint8_t *b_dev, 
 }
 
 extern "C" int mi355_prob_mean(const float *a_dev, const float *b_dev, float *out_dev, int64_t n, void *stream) {
+    MI355_TRY(bind_device());
     int64_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
@@ -572,16 +599,17 @@ extern "C" int mi355_prob_mean(const float *a_dev, const float *b_dev, float *ou
 extern "C" int mi355_zscore_masked(float *vol_dev, const uint8_t *mask_dev, int C, int64_t voxels, void *stream) {
     MI355_REQUIRE(C >= 1 && C <= 64, "zscore: %d channels", C);
     hipStream_t s = (hipStream_t)stream;
-    double *sums = nullptr;
-    MI355_HIP(hipMalloc(&sums, (size_t)C * 3 * sizeof(double)));
-    MI355_HIP(hipMemsetAsync(sums, 0, (size_t)C * 3 * sizeof(double), s));
     int64_t blocks = (voxels + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(masked_sums_kernel, dim3((unsigned)blocks, C), dim3(256), 0, s, vol_dev, mask_dev, voxels, sums);
+    // persistent scratch: [sums C x 3 | partial C x blocks x 3] doubles; asynchronous on `stream`
+    double *sums = nullptr;
+    MI355_TRY(device_scratch(SCR_SMALL, 1 << 20, (void **)&sums));
+    double *partial = nullptr;
+    MI355_TRY(device_scratch(SCR_ZSCORE, (size_t)C * blocks * 3 * sizeof(double), (void **)&partial));
+    hipLaunchKernelGGL(masked_sums_kernel, dim3((unsigned)blocks, C), dim3(256), 0, s, vol_dev, mask_dev, voxels, partial);
+    hipLaunchKernelGGL(masked_sums_finish_kernel, dim3(C), dim3(192), 0, s, partial, (int)blocks, sums);
     hipLaunchKernelGGL(masked_zscore_kernel, dim3((unsigned)blocks, C), dim3(256), 0, s, vol_dev, mask_dev, voxels, sums);
     MI355_HIP(hipGetLastError());
-    MI355_HIP(hipStreamSynchronize(s));
-    MI355_HIP(hipFree(sums));
     return MI355_OK;
 }

@@ -14,7 +14,8 @@ __global__ void label_remap_kernel(const uint8_t *in, uint8_t *out, int64_t n, B
         out[i] = map.m[in[i]];
 }
 
-// counts[p*K + g] += 1 for every voxel with pred label p, truth label g (labels >= K are clamped to K-1)
+// counts[p*K + g] += 1 for every voxel with pred label p, truth label g; bin K-1 is the "other" bin: it collects every
+// label >= K-1, so callers that care about labels 0..L pass K = L + 2 and out-of-range labels never alias a real one
 __global__ void confusion_kernel(const uint8_t *pred, const uint8_t *gt, int64_t n, int K, unsigned long long *counts) {
     __shared__ unsigned int local[64];
     if (threadIdx.x < 64) local[threadIdx.x] = 0;
@@ -84,6 +85,7 @@ using namespace mi355;
 
 extern "C" int mi355_label_remap(const uint8_t *in_dev, uint8_t *out_dev, int64_t n, const uint8_t *map256_host, void *stream) {
     MI355_REQUIRE(in_dev && out_dev && map256_host && n >= 0, "bad argument");
+    MI355_TRY(bind_device());
     ByteMap bm;
     for (int i = 0; i < 256; ++i) bm.m[i] = map256_host[i];
     int64_t blocks = (n + 255) / 256;
@@ -99,7 +101,7 @@ extern "C" int mi355_label_confusion(const uint8_t *pred_dev, const uint8_t *gt_
     MI355_REQUIRE(pred_dev && gt_dev && counts_host && K >= 2 && K <= 8, "bad argument (2 <= K <= 8)");
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *c = nullptr;
-    MI355_HIP(hipMalloc(&c, 64 * sizeof(unsigned long long)));
+    MI355_TRY(device_scratch(SCR_SMALL, 1 << 20, (void **)&c));
     MI355_HIP(hipMemsetAsync(c, 0, 64 * sizeof(unsigned long long), s));
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -108,7 +110,6 @@ extern "C" int mi355_label_confusion(const uint8_t *pred_dev, const uint8_t *gt_
     unsigned long long h[64];
     hipError_t e = hipMemcpyAsync(h, c, sizeof(h), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(c);
     MI355_HIP(e);
     for (int i = 0; i < K * K; ++i) counts_host[i] = h[i];
     return MI355_OK;
@@ -119,14 +120,13 @@ extern "C" int mi355_cosine_topk(const float *vectors_dev, const float *query_de
     MI355_REQUIRE(vectors_dev && query_dev && idx_host && scores_host && N >= 1 && D >= 1 && k >= 1 && k <= 64, "bad argument");
     if (k > N) k = N;
     hipStream_t s = (hipStream_t)stream;
-    float *scores = nullptr, *out_s = nullptr;
-    int *taken = nullptr, *out_i = nullptr;
-    unsigned long long *best = nullptr;
-    MI355_HIP(hipMalloc(&scores, (size_t)N * sizeof(float)));
-    MI355_HIP(hipMalloc(&out_s, 64 * sizeof(float)));
-    MI355_HIP(hipMalloc(&taken, 64 * sizeof(int)));
-    MI355_HIP(hipMalloc(&out_i, 64 * sizeof(int)));
-    MI355_HIP(hipMalloc(&best, sizeof(unsigned long long)));
+    // scratch: [best u64 | out_s 64 f32 | taken 64 i32 | out_i 64 i32 | scores N f32], persistent across calls
+    char *scr = nullptr;
+    MI355_TRY(device_scratch(SCR_TOPK, 1024 + (size_t)N * sizeof(float), (void **)&scr));
+    unsigned long long *best = (unsigned long long *)scr;
+    float *out_s = (float *)(scr + 64);
+    int *taken = (int *)(scr + 64 + 256), *out_i = (int *)(scr + 64 + 512);
+    float *scores = (float *)(scr + 1024);
     int blocks = (int)(((int64_t)N * 64 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(row_dot_kernel, dim3(blocks), dim3(256), 0, s, vectors_dev, query_dev, N, D, scores);
@@ -140,7 +140,6 @@ extern "C" int mi355_cosine_topk(const float *vectors_dev, const float *query_de
     hipError_t e = hipMemcpyAsync(idx_host, out_i, k * sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(scores_host, out_s, k * sizeof(float), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(scores); (void)hipFree(out_s); (void)hipFree(taken); (void)hipFree(out_i); (void)hipFree(best);
     MI355_HIP(e);
     return k;
 }
@@ -214,14 +213,15 @@ extern "C" int mi355_crop_mask(const float *vol_dev, int C, int Z, int Y, int X,
     MI355_REQUIRE(vol_dev && mask_dev && bbox_host && C >= 1 && Z >= 1 && Y >= 1 && X >= 1, "bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int64_t V = (int64_t)Z * Y * X;
-    uint8_t *state = nullptr;
-    int *flags = nullptr;  // [0] = changed, [1..6] = bbox
-    MI355_HIP(hipMalloc(&state, V));
-    MI355_HIP(hipMalloc(&flags, 8 * sizeof(int)));
+    char *scr = nullptr;   // persistent: [flags 8 i32 | pad to 256 | state V u8]
+    MI355_TRY(device_scratch(SCR_CROP, 256 + (size_t)V, (void **)&scr));
+    int *flags = (int *)scr;  // [0] = changed, [1..6] = bbox
+    uint8_t *state = (uint8_t *)(scr + 256);
     int64_t blocks = (V + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(nonzero_state_kernel, dim3((unsigned)blocks), dim3(256), 0, s, vol_dev, C, V, state);
     hipError_t e = hipGetLastError();
+    bool converged = false;
     for (int round = 0; e == hipSuccess && round < 4096; ++round) {
         (void)hipMemsetAsync(flags, 0, sizeof(int), s);
         for (int axis = 0; axis < 3; ++axis) {
@@ -231,7 +231,7 @@ extern "C" int mi355_crop_mask(const float *vol_dev, int C, int Z, int Y, int X,
         int changed = 0;
         e = hipMemcpyAsync(&changed, flags, sizeof(int), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (!changed) break;
+        if (e == hipSuccess && !changed) { converged = true; break; }
     }
     int init[7] = {0, 1 << 30, 1 << 30, 1 << 30, -1, -1, -1};
     if (e == hipSuccess) e = hipMemcpyAsync(flags, init, sizeof(init), hipMemcpyHostToDevice, s);
@@ -242,9 +242,8 @@ extern "C" int mi355_crop_mask(const float *vol_dev, int C, int Z, int Y, int X,
     int out[7];
     if (e == hipSuccess) e = hipMemcpyAsync(out, flags, sizeof(out), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(state);
-    (void)hipFree(flags);
     MI355_HIP(e);
+    MI355_REQUIRE(converged, "crop_mask: the border flood fill did not converge in 4096 rounds (%dx%dx%d)", Z, Y, X);
     MI355_REQUIRE(out[4] >= 0, "volume is all zeros: nothing to segment");
     for (int k = 0; k < 3; ++k) { bbox_host[2 * k] = out[1 + k]; bbox_host[2 * k + 1] = out[4 + k] + 1; }  // [lo, hi) per axis
     return MI355_OK;
@@ -288,7 +287,7 @@ extern "C" int mi355_label_stats(const uint8_t *seg_dev, int d0, int d1, int d2,
     hipStream_t s = (hipStream_t)stream;
     long long init[80], *dev = nullptr;
     for (int i = 0; i < 80; ++i) init[i] = (i % 10 >= 4 && i % 10 <= 6) ? (1ll << 40) : (i % 10 >= 7 ? -1 : 0);
-    MI355_HIP(hipMalloc(&dev, sizeof(init)));
+    MI355_TRY(device_scratch(SCR_SMALL, 1 << 20, (void **)&dev));
     hipError_t e = hipMemcpyAsync(dev, init, sizeof(init), hipMemcpyHostToDevice, s);
     const int64_t V = (int64_t)d0 * d1 * d2;
     int64_t blocks = (V + 255) / 256;
@@ -300,7 +299,6 @@ extern "C" int mi355_label_stats(const uint8_t *seg_dev, int d0, int d1, int d2,
     long long h[80];
     if (e == hipSuccess) e = hipMemcpyAsync(h, dev, sizeof(h), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(dev);
     MI355_HIP(e);
     long long nonzero = 0;
     for (int l = 1; l < K; ++l) nonzero += h[l * 10];

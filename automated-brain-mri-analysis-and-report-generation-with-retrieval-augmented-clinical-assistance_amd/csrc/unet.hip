@@ -69,15 +69,58 @@ struct mi355_unet {
 
 namespace mi355 {
 
-static int require_device() {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        set_error("no HIP device visible (%s); this library has no CPU fallback", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+static std::mutex g_mu;
+static int g_bound_device = -1;
+static struct { void *p; size_t bytes; } g_scratch[SCR_COUNT];
+
+static bool is_gfx950(int dev) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+int bind_device() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0) {
+        set_error("no HIP device visible (%s); this library has no CPU fallback", e == hipSuccess ? "none current" : hipGetErrorString(e));
         return MI355_ERR_NO_DEVICE;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_bound_device < 0) {
+        if (!is_gfx950(dev)) {
+            set_error("HIP device %d is not gfx950 (MI355X); this library has no other code path", dev);
+            return MI355_ERR_NO_DEVICE;
+        }
+        g_bound_device = dev;
+    } else if (g_bound_device != dev) {
+        set_error("this process is bound to HIP device %d but device %d is current: one process per GPU (weights, arena and "
+                  "scratch live on the bound device)", g_bound_device, dev);
+        return MI355_ERR_INVALID;
     }
     return MI355_OK;
 }
+
+int device_scratch(int slot, size_t bytes, void **out, bool zeroed) {
+    MI355_REQUIRE(slot >= 0 && slot < SCR_COUNT && out, "bad scratch slot %d", slot);
+    MI355_TRY(bind_device());
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto &b = g_scratch[slot];
+    if (b.bytes < bytes) {
+        if (b.p) {
+            MI355_HIP(hipDeviceSynchronize());  // work in flight may still use the old buffer
+            MI355_HIP(hipFree(b.p));
+            b.p = nullptr; b.bytes = 0;
+        }
+        MI355_HIP(hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+        if (zeroed) MI355_HIP(hipMemset(b.p, 0, bytes));
+    }
+    *out = b.p;
+    return MI355_OK;
+}
+
+static int require_device() { return bind_device(); }
 
 static int upload(const float *host, size_t n, float **dev) {
     MI355_HIP(hipMalloc(dev, n * sizeof(float)));
@@ -192,20 +235,10 @@ static int make_plan(const mi355_unet &net, int N, int D, int H, int W, Plan *pl
     return MI355_OK;
 }
 
-static char *g_arena = nullptr;
-static size_t g_arena_bytes = 0;
-
 static int ensure_arena(mi355_unet *net, size_t bytes) {
-    if (g_arena_bytes < bytes) {
-        if (g_arena) {
-            MI355_HIP(hipDeviceSynchronize());
-            MI355_HIP(hipFree(g_arena));
-            g_arena = nullptr; g_arena_bytes = 0;
-        }
-        MI355_HIP(hipMalloc(&g_arena, bytes));
-        g_arena_bytes = bytes;
-    }
-    net->arena = g_arena;
+    void *p = nullptr;
+    MI355_TRY(device_scratch(SCR_ARENA, bytes, &p));
+    net->arena = (char *)p;
     return MI355_OK;
 }
 
@@ -523,9 +556,10 @@ static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X,
 extern "C" const char *mi355_last_error(void) { return g_last_error.c_str(); }
 extern "C" int mi355_version(void) { return 100; }
 extern "C" int mi355_device_count(void) {
-    int n = 0;
+    int n = 0, good = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
+    for (int d = 0; d < n; ++d) good += is_gfx950(d) ? 1 : 0;
+    return good;
 }
 
 extern "C" int mi355_unet_create(const mi355_unet_desc *d, mi355_unet_t *out) {
@@ -623,6 +657,7 @@ extern "C" int64_t mi355_unet_flops(mi355_unet_t net, int d, int h, int w) {
 extern "C" int mi355_unet_forward(mi355_unet_t net, const float *x_dev, int n, int d, int h, int w, float *logits_dev,
                                   void *stream) {
     MI355_REQUIRE(net && x_dev && logits_dev && n > 0, "bad argument");
+    MI355_TRY(bind_device());
     hipStream_t s = (hipStream_t)stream;
     Plan pl;
     MI355_TRY(make_plan(*net, n, d, h, w, &pl));
@@ -686,6 +721,7 @@ extern "C" int mi355_compute_steps(int patch, int image, float step_size, int32_
 extern "C" int mi355_sw_partial(mi355_unet_t net, const float *vol_dev, int Z, int Y, int X, const mi355_sw_opts *opts,
                                 int rank, int world, float *agg_dev, float *cnt_dev, void *stream) {
     MI355_REQUIRE(net && vol_dev && opts && agg_dev && world >= 1 && rank >= 0 && rank < world, "bad argument");
+    MI355_TRY(bind_device());
     hipStream_t s = (hipStream_t)stream;
     SwGeom g;
     MI355_TRY(make_geom(*opts, Z, Y, X, &g));
@@ -705,6 +741,7 @@ extern "C" int mi355_sw_partial(mi355_unet_t net, const float *vol_dev, int Z, i
 
 extern "C" int mi355_sw_finish(const float *agg_dev, const float *cnt_dev, int num_classes, int Z, int Y, int X,
                                const int32_t patch[3], float *probs_dev, void *stream) {
+    MI355_TRY(bind_device());
     const int Zp = std::max(Z, patch[0]), Yp = std::max(Y, patch[1]), Xp = std::max(X, patch[2]);
     return finish_probs(agg_dev, cnt_dev, num_classes, Z, Y, X, Zp, Yp, Xp, (Zp - Z) / 2, (Yp - Y) / 2, (Xp - X) / 2,
                         probs_dev, 0, (hipStream_t)stream);
@@ -713,6 +750,7 @@ extern "C" int mi355_sw_finish(const float *agg_dev, const float *cnt_dev, int n
 extern "C" int mi355_sw_predict(const mi355_unet_t *nets, int n_nets, const float *vol_dev, int Z, int Y, int X,
                                 const mi355_sw_opts *opts, float *probs_dev, void *stream) {
     MI355_REQUIRE(nets && n_nets >= 1 && vol_dev && opts && probs_dev, "bad argument");
+    MI355_TRY(bind_device());
     hipStream_t s = (hipStream_t)stream;
     SwGeom g;
     MI355_TRY(make_geom(*opts, Z, Y, X, &g));
@@ -720,15 +758,9 @@ extern "C" int mi355_sw_predict(const mi355_unet_t *nets, int n_nets, const floa
     const size_t ZYXp = (size_t)g.Zp[0] * g.Zp[1] * g.Zp[2];
     // aggregation scratch: process-wide like the activation arena, grown on demand, never freed per call - a
     // hipMalloc / synchronise / hipFree round trip per volume costs more than the small kernels of a step
-    static float *g_sw_scratch = nullptr;
-    static size_t g_sw_scratch_floats = 0;
-    const size_t need = ZYXp * (size_t)(C + 1);
-    if (need > g_sw_scratch_floats) {
-        if (g_sw_scratch) { MI355_HIP(hipDeviceSynchronize()); MI355_HIP(hipFree(g_sw_scratch)); g_sw_scratch = nullptr; g_sw_scratch_floats = 0; }
-        MI355_HIP(hipMalloc(&g_sw_scratch, need * sizeof(float)));
-        g_sw_scratch_floats = need;
-    }
-    float *agg = g_sw_scratch, *cnt = g_sw_scratch + ZYXp * C;
+    void *scratch = nullptr;
+    MI355_TRY(device_scratch(SCR_SW_AGG, ZYXp * (size_t)(C + 1) * sizeof(float), &scratch));
+    float *agg = (float *)scratch, *cnt = agg + ZYXp * C;
     int rc = MI355_OK;
     for (int f = 0; f < n_nets && rc == MI355_OK; ++f) {
         if (nets[f]->num_classes != C) { set_error("fold %d has %d classes, fold 0 has %d", f, nets[f]->num_classes, C); rc = MI355_ERR_INVALID; break; }

@@ -90,7 +90,8 @@ def predict_case_single_threaded(model: LoadedModel, list_of_files, output_file,
     t0 = time.perf_counter()
     print(f"Preprocessing {output_file}")
     raw, like = read_case(list_of_files)
-    data, props = preprocessing.preprocess_case(raw)
+    # the plans decide what preprocessing means: anything this path does not implement is refused here
+    data, props = preprocessing.preprocess_case(raw, plans=model.folder.plans, spacing_zyx=tuple(reversed(like.zooms)))
     print(f"Data shape after preprocessing: {tuple(data.shape)}")
     print(f"Predicting {output_file}")
     t1 = time.perf_counter()
@@ -98,12 +99,7 @@ def predict_case_single_threaded(model: LoadedModel, list_of_files, output_file,
                                     model.nonlin)
     print(f"Ensembling {len(model.nets)} folds")
     lo = [b[0] for b in props["crop_bbox"]]
-    if model.folder.regions:
-        seg = ops.regions_to_labels(probs, (1, 2, 3), lo, props["original_size_of_raw_data"])
-    else:
-        seg = torch.zeros(props["original_size_of_raw_data"], dtype=torch.uint8, device=probs.device)
-        sz = probs.shape[1:]
-        seg[lo[0]:lo[0] + sz[0], lo[1]:lo[1] + sz[1], lo[2]:lo[2] + sz[2]] = probs.argmax(0).to(torch.uint8)
+    seg = ops.regions_to_labels(probs, (1, 2, 3) if model.folder.regions else None, lo, props["original_size_of_raw_data"])
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"Saving segmentation to {output_file}")

@@ -44,7 +44,7 @@ def apply_brats_threshold(seg, threshold=200, replace_with=2):
     """KAIST post-processing (archived/kaist_original_inference.py:33, ``apply_threshold_to_folder(..., 200, 2)``):
     a case with fewer than `threshold` voxels of label 3 (enhancing tumour) gets them relabelled to `replace_with`.
     seg: CUDA uint8 label map.  Returns (new label map, number of label-3 voxels found)."""
-    n3 = int(confusion(seg, seg, num_labels=4)[3, 3])  # one device pass over the label map
+    n3 = int(confusion(seg, seg, num_labels=5)[3, 3])  # one device pass; bin 4 = "other" keeps labels >= 4 out of bin 3
     if n3 >= threshold:
         return seg.clone(), n3
     import torch
@@ -58,8 +58,10 @@ def apply_brats_threshold(seg, threshold=200, replace_with=2):
     return out, n3
 
 
-def confusion(pred, gt, num_labels=5):
-    """K x K integer matrix, rows = predicted label, columns = ground truth."""
+def confusion(pred, gt, num_labels=6):
+    """K x K integer matrix, rows = predicted label, columns = ground truth.  The last bin (K-1) is "other": it
+    collects every label >= K-1 (the reference compares ``== label`` per label, evaluate_segmentation.py:20-21, so a
+    stray label must never be counted as a real one); the matrix always sums to the voxel count."""
     import torch
     if pred.shape != gt.shape or pred.dtype != torch.uint8 or gt.dtype != torch.uint8:
         raise ValueError("confusion: two uint8 tensors of equal shape expected (evaluate_segmentation.py:78-81)")
@@ -107,7 +109,7 @@ def metrics_from_confusion(cm, labels=(1, 2, 3)):
 
 def evaluate(pred, gt):
     """pred, gt: CUDA uint8 label maps in the BraTS convention -> metrics dict."""
-    return metrics_from_confusion(confusion(pred, gt, 5))
+    return metrics_from_confusion(confusion(pred, gt, 6))  # labels 0..4 + "other"
 
 
 # ---- feature_extraction/utils.py:167-216 on the device --------------------------------------------------------

@@ -25,13 +25,14 @@ def _require_cuda(t, dtype, name):
 
 def regions_to_labels(probs, order=(1, 2, 3), bbox_lo=(0, 0, 0), full_shape=None):
     """seg = 0; seg[probs[i] > 0.5] = order[i] in order; pasted at bbox_lo of a zero uint8 volume of
-    full_shape (reference driver :144-156, region_class_order=(1,2,3))."""
+    full_shape (reference driver :144-156, region_class_order=(1,2,3)).  ``order=None``: seg = argmax over channels
+    (the same export for trainers without regions)."""
     import torch
     probs = _require_cuda(probs, torch.float32, "probs")
     c, z, y, x = probs.shape
     full = tuple(full_shape) if full_shape is not None else (z, y, x)
     out = torch.empty(full, dtype=torch.uint8, device=probs.device)
-    order_a = (C.c_int32 * len(order))(*[int(v) for v in order])
+    order_a = None if order is None else (C.c_int32 * len(order))(*[int(v) for v in order])
     lo = (C.c_int32 * 3)(*[int(v) for v in bbox_lo])
     fu = (C.c_int32 * 3)(*[int(v) for v in full])
     _lib.check(_lib.load().mi355_regions_to_labels(probs.data_ptr(), c, z, y, x, order_a, lo, fu, out.data_ptr(),

@@ -80,10 +80,8 @@ def predict_preprocessed_data_return_seg_and_softmax(net: UNet, data, do_mirrori
         raise NotImplementedError("the reference path always uses the sliding window (driver :101)")
     probs = predict_folds([net], data, patch_size, step_size, do_mirroring, mirror_axes, use_gaussian, nonlin,
                           batch_tiles)
-    if regions_class_order is None:
-        seg = probs.argmax(0).to(probs.dtype)  # argmax variant documented at PROJECT_DOCUMENTATION.md:325-344
-    else:
-        seg = ops.regions_to_labels(probs, regions_class_order)
+    # regions_class_order=None: argmax variant documented at PROJECT_DOCUMENTATION.md:325-344
+    seg = ops.regions_to_labels(probs, regions_class_order)
     return seg, probs
 
 

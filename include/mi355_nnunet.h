@@ -16,7 +16,7 @@
  *   mi355_regions_to_labels  save_segmentation_nifti_from_softmax(..., region_class_order=(1,2,3))
  *                            called at run_brats2021_inference_singlethread.py:144-156
  *   mi355_label_ensemble     run_brats2021_inference_singlethread.py:299-305  np.round((s1+s2)/2)
- *   mi355_prob_mean_threshold archived/kaist_original_inference.py:30-32 (nnUNet_ensemble mode)
+ *   mi355_prob_mean          archived/kaist_original_inference.py:30-32 (nnUNet_ensemble: mean of two softmax volumes)
  *   mi355_zscore_masked      trainer.preprocess_patient -> nonCT + use_mask_for_norm normalisation,
  *                            called at run_brats2021_inference_singlethread.py:89
  *
@@ -24,8 +24,11 @@
  * mi355_last_error() gives the message of the calling thread's last failure.
  * All "dev" pointers are device (HBM) pointers on the current HIP device; the caller
  * owns them.  The library owns its weights and activation arena.  `stream` is a
- * hipStream_t passed as void* (NULL = default stream).  One handle per (device, model);
- * a handle must not be used from two threads at once.  There is NO CPU fallback: on a
+ * hipStream_t passed as void* (NULL = default stream).  ONE PROCESS PER GPU: the library binds
+ * to the HIP device that is current at its first compute call (weights, arena and scratch
+ * buffers live there) and every later call fails with MI355_ERR_INVALID while another device
+ * is current.  The arena and scratch are shared by all handles: issue work on one stream at a
+ * time; a handle must not be used from two threads at once.  There is NO CPU fallback: on a
  * machine without a gfx950 device every compute entry point fails with MI355_ERR_NO_DEVICE.
  */
 #ifndef MI355_NNUNET_H
@@ -99,7 +102,7 @@ typedef struct {
 
 const char *mi355_last_error(void);
 int mi355_version(void);
-/* number of visible gfx950 devices (0 if none / no HIP runtime device) */
+/* number of visible gfx950 devices (0 if none / no HIP runtime device); other architectures are not counted */
 int mi355_device_count(void);
 
 int mi355_unet_create(const mi355_unet_desc *desc, mi355_unet_t *out);
@@ -133,7 +136,8 @@ int mi355_sw_finish(const float *agg_dev, const float *cnt_dev, int num_classes,
                     const int32_t patch[3], float *probs_dev, void *stream);
 
 /* seg = 0; for i in 0..C-1: seg[probs[i] > 0.5] = order[i]; pasted at bbox_lo into a zeroed
- * [full_z][full_y][full_x] uint8 volume. */
+ * [full_z][full_y][full_x] uint8 volume.  order == NULL: seg = argmax over the C channels (first maximum wins), what
+ * the same export does for trainers without regions (region_class_order=None). */
 int mi355_regions_to_labels(const float *probs_dev, int C, int Z, int Y, int X, const int32_t *order,
                             const int32_t bbox_lo[3], const int32_t full[3], uint8_t *labels_dev,
                             void *stream);
@@ -149,7 +153,9 @@ int mi355_zscore_masked(float *vol_dev, const uint8_t *mask_dev, int C, int64_t 
 /* out[i] = map[in[i]] (convert_labels_to_brats.py:34-55: nnU-Net {1,2,3} -> BraTS2025 {2,1,3} / BraTS2021 {2,1,4}). */
 int mi355_label_remap(const uint8_t *in_dev, uint8_t *out_dev, int64_t n, const uint8_t *map256_host, void *stream);
 /* counts_host[p*K+g] = #voxels with prediction p and ground truth g: everything evaluate_segmentation.py:12-49,
- * 129-195 derives (Dice, IoU, sensitivity, specificity per label and for WT/TC/ET) follows from these integers. */
+ * 129-195 derives (Dice, IoU, sensitivity, specificity per label and for WT/TC/ET) follows from these integers.
+ * Bin K-1 is the "other" bin: it collects every label >= K-1, so pass K = (largest label of interest) + 2 and no
+ * out-of-range label is ever counted as a real one; the K*K counts always sum to n.  2 <= K <= 8. */
 int mi355_label_confusion(const uint8_t *pred_dev, const uint8_t *gt_dev, int64_t n, int K, uint64_t *counts_host,
                           void *stream);
 /* scores = V @ q over L2-normalised rows, top-k by score (RAG_Assistant/rag_assistant.py:197-211).

@@ -108,3 +108,26 @@ def test_missing_model_dir_exits_1(amd, tmp_path):
     with pytest.raises(SystemExit) as e:
         amd.driver.run_model_single_threaded(tmp_path / "nope", tmp_path, tmp_path / "out")
     assert e.value.code == 1
+
+
+def test_plans_are_checked_not_assumed(amd):
+    """the plans decide what preprocessing means; anything this path does not implement is refused."""
+    pp, ck = amd.preprocessing, amd.checkpoint
+    plans = ck.default_brats_plans()
+    assert pp.check_plans(plans, 4) == [True] * 4 and pp.check_plans(None, 4) == [True] * 4
+    pp.check_spacing(plans, (1.0, 1.0, 1.0), (140, 171, 137))
+    pp.check_spacing(plans, (1.0, 1.0004, 1.0), (140, 171, 137))      # nnU-Net: round(spacing ratio * shape) == shape -> no resample
+    with pytest.raises(pp.UnsupportedPlansError, match="resampl"):
+        pp.check_spacing(plans, (2.0, 2.0, 2.0), (78, 120, 120))       # a 2 mm header (e.g. an api.py upload)
+    with pytest.raises(pp.UnsupportedPlansError, match="transpose_forward"):
+        pp.check_plans({**plans, "transpose_forward": [2, 0, 1]}, 4)
+    with pytest.raises(pp.UnsupportedPlansError, match="CT"):
+        pp.check_plans({**plans, "normalization_schemes": {0: "CT", 1: "nonCT", 2: "nonCT", 3: "nonCT"}}, 4)
+    with pytest.raises(pp.UnsupportedPlansError, match="modalities"):
+        pp.check_plans(plans, 3)
+    mixed = pp.check_plans({**plans, "use_mask_for_norm": {0: True, 1: False, 2: True, 3: False}}, 4)
+    assert mixed == [True, False, True, False]
+    other = {**plans, "plans_per_stage": {0: {**plans["plans_per_stage"][0], "current_spacing": np.array([2.0, 1.0, 1.0])}}}
+    pp.check_spacing(other, (2.0, 1.0, 1.0), (70, 171, 137))
+    with pytest.raises(pp.UnsupportedPlansError):
+        pp.check_spacing(other, (1.0, 1.0, 1.0), (140, 171, 137))
