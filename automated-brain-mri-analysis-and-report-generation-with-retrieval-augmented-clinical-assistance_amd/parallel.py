@@ -72,6 +72,31 @@ def gather_label_maps(seg, group=None):
     return out
 
 
+def predict_cases_sharded(models, cases, rank: int, world: int, patch_size=(128, 128, 128), step_size=0.5,
+                          do_mirroring=True, mirror_axes=(0, 1, 2), nonlin="sigmoid", region_order=(1, 2, 3)):
+    """Partitioning A (BASELINE.json configs[3]): this rank's share of a batch of cases, no data-path collective.
+
+    ``models`` is a list of ensemble members, each a list of fold networks (the reference runs model 1 then model 2
+    with five folds each, driver :263-264); ``cases[i]`` is ``(data, props)`` as ``preprocess_case`` returns it, or a
+    callable producing that (so a rank only materialises its own cases).  Per case: fold-mean probabilities per
+    member (driver :128), region labels pasted at the crop box (:144-156), label-round ensemble of two members
+    (:305).  Returns ``{case index: uint8 label volume on the device}`` for the cases with ``index % world == rank``.
+    """
+    from . import ops, predictor
+    if len(models) not in (1, 2):
+        raise ValueError("the reference ensembles one or two members (label-round ensemble is pairwise)")
+    out = {}
+    for i in shard_cases(len(cases), rank, world):
+        data, props = cases[i]() if callable(cases[i]) else cases[i]
+        lo = [b[0] for b in props["crop_bbox"]]
+        segs = []
+        for folds in models:
+            probs = predictor.predict_folds(folds, data, patch_size, step_size, do_mirroring, mirror_axes, True, nonlin)
+            segs.append(ops.regions_to_labels(probs, region_order, lo, props["original_size_of_raw_data"]))
+        out[i] = segs[0] if len(segs) == 1 else ops.label_ensemble(segs[0], segs[1])
+    return out
+
+
 def predict_case_tile_sharded(net, data, patch_size=(128, 128, 128), step_size=0.5, do_mirroring=True,
                               mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid", group=None):
     """Partitioning B end to end on the GPU ranks of ``group``: identical probabilities on every rank."""

@@ -5,17 +5,28 @@ One "step" = one pass of the hot path over one synthetic BraTS-shaped volume tha
 preprocessed and resident in HBM: tile gather -> U-Net forwards -> sigmoid -> Gaussian-weighted
 aggregation -> probabilities -> region labels pasted into the full 155x240x240 uint8 volume.
 Default workload = BASELINE.json configs[1]: one 4x240x240x155 volume, 128^3 patches, step 0.5,
-model A (base 32, BatchNorm), 1 fold, fp32, no TTA -> 8 forwards per volume.
+model A (base 32, BatchNorm), 1 fold, fp32, no TTA -> 8 forwards per volume.  The default run also
+carries, inside the same JSON line, `secondary` blocks for BASELINE.json configs[2] (8-way TTA,
+models A + B, label ensemble) in fp16 and fp32 and an `end_to_end` block (host volume -> H2D ->
+crop -> z-score -> predict -> labels -> D2H).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--dtype f32|f16]
+                    [--no-cpu-baseline] [--no-secondary]
 
-For N > 1 the driver launches it under torch.distributed.run; every rank processes its own
-volume (cases are the sharding unit: SURVEY.md 8e partitioning A, no data-path collective),
-timing is barrier + synchronize bracketed and the maximum over ranks.
+--config 4 = BASELINE.json configs[3]: a batch of 32 synthetic volumes (seeds 1000..1031), config-3
+settings, CASES sharded round-robin over the ranks (SURVEY.md 8e partitioning A, no data-path
+collective); one step = the whole batch, so this workload scales strongly.
+
+For N > 1 the driver launches this file under torch.distributed.run; when it is started plainly
+with --gpus N > 1 it starts that launcher itself as a child process BEFORE anything touches the
+GPU and relays the child's output and exit code.  Timing is barrier + synchronize bracketed and the
+maximum over ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,91 +38,134 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, same guide
 PEAK_HBM_GBS = 8000.0
+PATCH = (128, 128, 128)
+# Winograd kernels execute fewer multiplies than the algorithmic (direct-convolution) count that `achieved` uses:
+# F(2,3) along y issues 2/3 of the direct MFMAs, F(2x2,3x3) over (z,y) 4/9; frac can therefore exceed 1 and
+# frac_executed = matrix-pipe utilisation is reported beside it.
+EXECUTED_RATIO = {"conv3_f32_wino_kernel": 2.0 / 3.0, "conv3_f32_wino2_kernel": 4.0 / 9.0}
+
+WORKLOADS = {
+    2: dict(models=[("A", 7)], tta=False, dtype="f32",
+            name="BASELINE.json configs[1]: 1 volume 4x240x240x155, 128^3 patches, step 0.5, model A, 1 fold, no TTA"),
+    3: dict(models=[("A", 7), ("B", 8)], tta=True, dtype="f16",
+            name="BASELINE.json configs[2]: 1 volume, 8-way mirror TTA, models A+B, 1 fold each, label-round ensemble"),
+    4: dict(models=[("A", 7), ("B", 8)], tta=True, dtype="f16", n_cases=32,
+            name="BASELINE.json configs[3]: batch of 32 synthetic volumes (seeds 1000-1031), 8-way mirror TTA, models A+B, "
+                 "1 fold each, label-round ensemble, cases sharded over the ranks"),
+}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="BASELINE.json config (1-based)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4), help="BASELINE.json config (1-based)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 and end-to-end blocks of the default run")
     ap.add_argument("--batch-tiles", type=int, default=0)
-    ap.add_argument("--dtype", choices=("f32", "f16"), default=None, help="default: f32 for config 2, f16 for config 3")
-    args = ap.parse_args()
+    ap.add_argument("--cases", type=int, default=0, help="config 4: number of volumes in the batch (default 32)")
+    ap.add_argument("--dtype", choices=("f32", "f16"), default=None, help="default: f32 for config 2, f16 for configs 3 and 4")
+    # rehearsal of the N > 1 launch path on a box with fewer GPUs than ranks: ranks share device 0 and synchronise
+    # over gloo (RCCL refuses two ranks on one device); never used by the driver
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
+
+def launch_command(n_gpus, argv, port=None):
+    """The command the driver itself uses for N > 1 (one rank per GPU over RCCL)."""
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr",
+            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(args, argv):
+    """--gpus N > 1 without a launcher: become the launcher's parent.  Nothing in this process has touched HIP yet
+    (torch is not even imported), so starting children is safe; we never exec."""
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        proc = subprocess.run(launch_command(args.gpus, argv), env=env)
+        sys.exit(proc.returncode)
+
+
+class Ctx:
+    """Process-level state of one bench run (rank, device, collective helpers)."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        dev_index = 0 if args.share_gpu else self.local_rank
+        torch.cuda.set_device(dev_index)
+        self.device = torch.device("cuda", dev_index)
+        self.use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run (any N)
+        self.backend = args.backend
+        if self.use_dist:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.device)
+            else:
+                dist.init_process_group("gloo")
+
+    def sync_all(self):
+        self.torch.cuda.synchronize(self.device)
+        if self.use_dist:
+            if self.backend == "nccl":
+                self.dist.barrier(device_ids=[self.device.index])
+            else:
+                self.dist.barrier()
+            self.torch.cuda.synchronize(self.device)
+
+    def max_over_ranks(self, seconds):
+        if not self.use_dist:
+            return seconds
+        dev = self.device if self.backend == "nccl" else "cpu"
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.use_dist:
+            self.dist.destroy_process_group()
+
+
+def build_nets(models, dtype):
     import brats_amd
-    from brats_amd import synthetic, predictor, preprocessing, ops
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run (any N)
-    if use_dist:
-        dist.init_process_group("nccl", device_id=device)
-
-    # ---- workload
-    patch = (128, 128, 128)
-    dtype = args.dtype or ("f32" if args.config == 2 else "f16")
-    if args.config == 2:
-        models = [("A", 7)]
-        do_mirroring = False
-        workload = "BASELINE.json configs[1]: 1 volume 4x240x240x155, 128^3 patches, step 0.5, model A, 1 fold, no TTA"
-    else:
-        models = [("A", 7), ("B", 8)]
-        do_mirroring = True
-        workload = "BASELINE.json configs[2]: 1 volume, 8-way mirror TTA, models A+B, 1 fold each, label-round ensemble"
+    from brats_amd import synthetic
     nets = []
     for name, seed in models:
         sd, meta = synthetic.make_model(name, seed=seed)
         nets.append(brats_amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"], dtype=dtype))
         del sd
-    raw = synthetic.make_volume(seed=1000 + rank)
-    data, props = preprocessing.preprocess_case(raw, device)
-    full = props["original_size_of_raw_data"]
-    lo = [b[0] for b in props["crop_bbox"]]
-    steps_tbl = [ops.compute_steps(patch[a], max(patch[a], data.shape[1 + a]), 0.5) for a in range(3)]
-    n_tiles = int(np.prod([len(s) for s in steps_tbl]))
-    n_mirrors = 8 if do_mirroring else 1
-    flops_per_volume = sum(n.flops(patch) for n in nets) * n_tiles * n_mirrors
+    return nets
 
-    def step():
-        segs = []
-        for net in nets:
-            probs = predictor.predict_folds([net], data, patch, 0.5, do_mirroring, (0, 1, 2), True, "sigmoid",
-                                            batch_tiles=args.batch_tiles)
-            segs.append(ops.regions_to_labels(probs, (1, 2, 3), lo, full))
-        return segs[0] if len(segs) == 1 else ops.label_ensemble(segs[0], segs[1])
 
-    def sync_all():
-        torch.cuda.synchronize(device)
-        if use_dist:
-            dist.barrier(device_ids=[local_rank])
-            torch.cuda.synchronize(device)
-
-    for _ in range(args.warmup):
-        seg = step()
+def timed_region(ctx, step, steps, warmup, nets):
+    """W untimed steps, then exactly K steps between two barrier + synchronize brackets; per-kernel HIP-event
+    profile of the timed steps (events recorded by the library on the launch stream)."""
+    out = None
+    for _ in range(warmup):
+        out = step()
     for net in nets:
         net.profile(True)
-    sync_all()
+    ctx.sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        seg = step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    for _ in range(steps):
+        out = step()
+    ctx.sync_all()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
     prof = {}
     for net in nets:
         for e in net.read_profile():
@@ -119,98 +173,287 @@ def main():
             for k in ("launches", "ms", "flops", "bytes"):
                 p[k] += e[k]
         net.profile(False)
-    label_hist = torch.bincount(seg.flatten().to(torch.int64), minlength=4).tolist()
+    return elapsed, prof, out
 
-    if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
-        return
 
-    # ---- roofline of the dominant kernel (HIP events on the launch stream, this timed region)
+def roofline_of(prof, dtype, traffic_ok):
+    """Roofline of the kernel with the largest summed HIP-event time over the timed region."""
     dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = dom["ms"] / dom["launches"]
-    achieved_tflops = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+    achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_file):
+    if traffic_ok and os.path.exists(pmc_file):  # the committed PMC passes were taken on the default workload's launch sizes
         try:
             traffic = json.load(open(pmc_file)).get(dom_name, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_F16_MFMA_TFLOPS
-    # Winograd kernels execute fewer multiplies than the algorithmic (direct-convolution) count that `achieved` uses:
-    # F(2,3) along y issues 2/3 of the direct MFMAs, F(2x2,3x3) over (z,y) 4/9; frac can therefore exceed 1 and
-    # frac_executed = matrix-pipe utilisation is reported beside it.
-    executed_ratio = {"conv3_f32_wino_kernel": 2.0 / 3.0, "conv3_f32_wino2_kernel": 4.0 / 9.0}.get(dom_name, 1.0)
-    if args.config != 2 or args.batch_tiles:
-        traffic = None  # the committed PMC passes were taken on the default workload's launch sizes
-    roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved_tflops, 2), peak=peak,
-                    unit="TFLOP/s", frac=round(achieved_tflops / peak, 4), traffic=traffic,
-                    executed_flop_ratio=round(executed_ratio, 4),
-                    frac_executed=round(achieved_tflops * executed_ratio / peak, 4),
-                    launches=dom["launches"], avg_launch_ms=round(avg_ms, 4),
-                    algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3),
-                    algorithmic_mb_per_launch=round(dom["bytes"] / dom["launches"] / 1e6, 2),
-                    time_share=round(dom["ms"] / sum(p["ms"] for p in prof.values()), 4))
-    kernels = {k: dict(launches=v["launches"], ms_total=round(v["ms"], 3),
-                       tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
-                       gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None)
-               for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    ratio = EXECUTED_RATIO.get(dom_name, 1.0)
+    conv_ms = sum(v["ms"] for k, v in prof.items() if v["flops"] > 0)
+    conv_flops = sum(v["flops"] for v in prof.values())
+    return dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                frac=round(achieved / peak, 4), traffic=traffic, executed_flop_ratio=round(ratio, 4),
+                frac_executed=round(achieved * ratio / peak, 4), launches=dom["launches"], avg_launch_ms=round(avg_ms, 4),
+                algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3),
+                algorithmic_mb_per_launch=round(dom["bytes"] / dom["launches"] / 1e6, 2),
+                time_share=round(dom["ms"] / sum(p["ms"] for p in prof.values()), 4),
+                # all conv / transposed-conv launches of the timed region together: algorithmic flops / their summed time
+                conv_stages_frac=round(conv_flops / (conv_ms * 1e-3) / 1e12 / peak, 4) if conv_ms > 0 else None)
 
-    # ---- CPU baseline: the oracle on this host's cores, bounded sample of the same workload
-    cpu = None
-    parity = None
-    if not args.no_cpu_baseline and world == 1:
-        from oracle import unet_ref, tiler_ref
-        sd, meta = synthetic.make_model(models[0][0], seed=models[0][1])
+
+def kernel_table(prof):
+    return {k: dict(launches=v["launches"], ms_total=round(v["ms"], 3),
+                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
+                    gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None)
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+
+
+def first_tile(data, steps_tbl):
+    """The first 128^3 tile of the sliding window (zero-padded like the tiler pads), [1, C, 128, 128, 128]."""
+    import torch
+    z0, y0, x0 = steps_tbl[0][0], steps_tbl[1][0], steps_tbl[2][0]
+    tile = data[:, z0:z0 + PATCH[0], y0:y0 + PATCH[1], x0:x0 + PATCH[2]]
+    pad = [PATCH[i] - tile.shape[1 + i] for i in range(3)]
+    return torch.nn.functional.pad(tile, (0, pad[2], 0, pad[1], 0, pad[0]))[None].contiguous()
+
+
+class CpuOracle:
+    """The CPU oracle (oracle/unet_ref.py, torch-CPU fp32) on a real tile of the timed volume: its timed forwards are
+    the `cpu_baseline`, their outputs the parity reference for every GPU configuration of this run."""
+
+    def __init__(self, tile):
+        self.x = tile.cpu()
+        self.logits = {}
+        self.seconds = {}
+
+    def forward(self, name, seed, min_forwards=1, budget_s=0.0):
+        import torch
+        from brats_amd import synthetic
+        from oracle import unet_ref
+        if name in self.logits:
+            return self.logits[name]
+        sd, meta = synthetic.make_model(name, seed=seed)
         cfg = unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])
-        # the sample is a REAL tile of this step's volume (first tile of the sliding window), so the timed CPU
-        # forwards double as the parity check of the GPU path on the same input
-        z0, y0, x0 = steps_tbl[0][0], steps_tbl[1][0], steps_tbl[2][0]
-        tile = data[:, z0:z0 + patch[0], y0:y0 + patch[1], x0:x0 + patch[2]]
-        pad = [patch[i] - tile.shape[1 + i] for i in range(3)]
-        tile = torch.nn.functional.pad(tile, (0, pad[2], 0, pad[1], 0, pad[0]))[None].contiguous()
-        x = tile.cpu()
-        cores = torch.get_num_threads()
-        unet_ref.unet_forward(sd, x[:, :, :64, :64, :64], cfg)  # page in
-        n_fw = 0
-        tc0 = time.perf_counter()
-        ref_logits = None
-        while n_fw < 2 or (time.perf_counter() - tc0 < 10.0 and n_fw < 6):
-            ref_logits = unet_ref.unet_forward(sd, x, cfg)
-            n_fw += 1
-        per_fw = (time.perf_counter() - tc0) / n_fw
-        cpu_flops_model0 = nets[0].flops(patch)
-        est_volume_s = per_fw * flops_per_volume / cpu_flops_model0
-        got_logits = nets[0](tile).cpu()
-        pr, pg = torch.sigmoid(ref_logits)[0].numpy(), torch.sigmoid(got_logits)[0].numpy()
-        dice_tile = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(pg), tiler_ref.regions_to_labels(pr))
-        parity = dict(sample="first 128^3 tile of the timed volume, GPU forward vs the CPU oracle forward",
-                      max_abs_prob_err=float(np.abs(pg - pr).max()),
-                      max_abs_logit_err=float((got_logits - ref_logits).abs().max()), logit_std=float(ref_logits.std()),
-                      dice_wt_tc_et_mean=round(dice_tile["mean"], 6))
-        cpu = dict(value=round(1.0 / est_volume_s, 6), unit="volumes/s", cores=cores, kind="port",
-                   sample=f"{n_fw} forwards of model {models[0][0]} on the first 1x4x128^3 tile of the timed volume with the torch-CPU fp32 oracle "
-                          f"({per_fw:.2f} s each), scaled by flops to the {n_tiles * n_mirrors * len(nets)} forwards of one volume",
-                   seconds_per_volume_est=round(est_volume_s, 2))
+        if not self.logits:
+            unet_ref.unet_forward(sd, self.x[:, :, :64, :64, :64], cfg)  # page in
+        n, t0 = 0, time.perf_counter()
+        while n < min_forwards or (time.perf_counter() - t0 < budget_s and n < 6):
+            out = unet_ref.unet_forward(sd, self.x, cfg)
+            n += 1
+        self.seconds[name] = ((time.perf_counter() - t0) / n, n)
+        self.logits[name] = out
+        self.cores = torch.get_num_threads()
+        return out
 
-    value = world * args.steps / elapsed
+
+def parity_block(got_logits, ref_logits, sample):
+    import torch
+    from oracle import tiler_ref
+    pr, pg = torch.sigmoid(ref_logits)[0].numpy(), torch.sigmoid(got_logits)[0].numpy()
+    d = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(pg), tiler_ref.regions_to_labels(pr))
+    return dict(sample=sample, max_abs_prob_err=float(np.abs(pg - pr).max()),
+                max_abs_logit_err=float((got_logits - ref_logits).abs().max()), logit_std=float(ref_logits.std()),
+                dice_wt_tc_et_mean=round(d["mean"], 6))
+
+
+def run_single_volume(ctx, args, config, dtype, steps, warmup, data, props, steps_tbl, oracle=None):
+    """configs 2 / 3: one volume per rank per step.  Returns the result dict (without the top-level contract keys)."""
+    from brats_amd import predictor, ops
+    wl = WORKLOADS[config]
+    nets = build_nets(wl["models"], dtype)
+    full = props["original_size_of_raw_data"]
+    lo = [b[0] for b in props["crop_bbox"]]
+    n_tiles = int(np.prod([len(s) for s in steps_tbl]))
+    n_mirrors = 8 if wl["tta"] else 1
+    flops_per_volume = sum(n.flops(PATCH) for n in nets) * n_tiles * n_mirrors
+
+    def step():
+        segs = []
+        for net in nets:
+            probs = predictor.predict_folds([net], data, PATCH, 0.5, wl["tta"], (0, 1, 2), True, "sigmoid",
+                                            batch_tiles=args.batch_tiles)
+            segs.append(ops.regions_to_labels(probs, (1, 2, 3), lo, full))
+        return segs[0] if len(segs) == 1 else ops.label_ensemble(segs[0], segs[1])
+
+    elapsed, prof, seg = timed_region(ctx, step, steps, warmup, nets)
+    res = dict(dtype=dtype, steps=steps, warmup=warmup, ms_per_step=round(elapsed / steps * 1e3, 3),
+               volumes_per_s=round(ctx.world * steps / elapsed, 4),
+               config={"workload": wl["name"], "patch": list(PATCH), "tiles_per_volume": n_tiles, "mirrors": n_mirrors,
+                       "models": [m[0] for m in wl["models"]], "crop": list(data.shape[1:]),
+                       "sharding": "cases (one volume per rank per step)", "tflop_per_volume": round(flops_per_volume / 1e12, 3)},
+               sustained_tflops_per_gpu=round(flops_per_volume * steps / elapsed / 1e12, 2),
+               roofline=roofline_of(prof, dtype, traffic_ok=(config == 2 and dtype == "f32" and not args.batch_tiles)),
+               kernels=kernel_table(prof),
+               label_histogram=ctx.torch.bincount(seg.flatten().to(ctx.torch.int64), minlength=4).tolist(),
+               speedup_vs_nominal_5min=round(300.0 / (elapsed / steps), 1))
+    res["_flops_per_volume"] = flops_per_volume
+    res["_elapsed"] = elapsed
+    if oracle is not None and ctx.rank == 0:
+        tile = first_tile(data, steps_tbl)
+        par = {}
+        for (name, seed), net in zip(wl["models"], nets):
+            ref = oracle.forward(name, seed)
+            par[name] = parity_block(net(tile).cpu(), ref, f"first 128^3 tile of the timed volume, model {name} {dtype} GPU forward vs the CPU oracle forward")
+        res["parity_vs_cpu_ref"] = par if len(par) > 1 else next(iter(par.values()))
+    for n in nets:
+        n.close()
+    return res
+
+
+def run_end_to_end(ctx, raw, steps=3):
+    """Host float32 volume -> H2D -> crop mask + bbox -> masked z-score -> sliding window (config 2) -> labels -> D2H."""
+    from brats_amd import preprocessing, predictor, ops
+    nets = build_nets(WORKLOADS[2]["models"], "f32")
+    torch = ctx.torch
+
+    def once():
+        t = [time.perf_counter()]
+        data, props = preprocessing.preprocess_case(raw, ctx.device)
+        torch.cuda.synchronize(ctx.device)
+        t.append(time.perf_counter())
+        probs = predictor.predict_folds(nets, data, PATCH, 0.5, False, (0, 1, 2), True, "sigmoid")
+        seg = ops.regions_to_labels(probs, (1, 2, 3), [b[0] for b in props["crop_bbox"]], props["original_size_of_raw_data"])
+        torch.cuda.synchronize(ctx.device)
+        t.append(time.perf_counter())
+        host = seg.cpu()
+        t.append(time.perf_counter())
+        return [b - a for a, b in zip(t[:-1], t[1:])], host
+
+    once()
+    parts = np.array([once()[0] for _ in range(steps)])
+    m = parts.mean(0)
+    for n in nets:
+        n.close()
+    return dict(workload="config 2 from a host fp32 [4,155,240,240] array to a host uint8 label volume (PCIe-inclusive; never `value`)",
+                steps=steps, ms_total=round(float(m.sum()) * 1e3, 2), ms_h2d_crop_zscore=round(float(m[0]) * 1e3, 2),
+                ms_predict_labels=round(float(m[1]) * 1e3, 2), ms_labels_d2h=round(float(m[2]) * 1e3, 2),
+                volumes_per_s=round(1.0 / float(m.sum()), 3))
+
+
+def run_config4(ctx, args, dtype):
+    """BASELINE.json configs[3]: the batch is fixed (32 volumes), ranks take cases round-robin; a step = the batch."""
+    from brats_amd import synthetic, preprocessing, parallel
+    wl = WORKLOADS[4]
+    n_cases = args.cases or wl["n_cases"]
+    nets = build_nets(wl["models"], dtype)
+    mine = parallel.shard_cases(n_cases, ctx.rank, ctx.world)
+    cases = [None] * n_cases
+    for i in mine:  # every rank generates and preprocesses only its own shard, outside the timed region
+        cases[i] = preprocessing.preprocess_case(synthetic.make_volume(seed=1000 + i), ctx.device)
+    tiles = mirrors = 0
+    flops_batch = 0
+    from brats_amd import ops
+    for i in range(n_cases):
+        if cases[i] is None:
+            continue
+        shp = cases[i][0].shape[1:]
+        nt = int(np.prod([len(ops.compute_steps(PATCH[a], max(PATCH[a], shp[a]), 0.5)) for a in range(3)]))
+        flops_batch += sum(n.flops(PATCH) for n in nets) * nt * 8
+        tiles += nt
+    if ctx.use_dist:  # host-side bookkeeping only (not in the timed region, not on the data path)
+        dev = ctx.device if ctx.backend == "nccl" else "cpu"
+        t = ctx.torch.tensor([float(flops_batch), float(tiles)], dtype=ctx.torch.float64, device=dev)
+        ctx.dist.all_reduce(t)
+        flops_batch, tiles = float(t[0].item()), int(t[1].item())
+
+    def step():
+        return parallel.predict_cases_sharded([[n] for n in nets], cases, ctx.rank, ctx.world, PATCH, 0.5, True)
+
+    elapsed, prof, segs = timed_region(ctx, step, args.steps, args.warmup, nets)
+    hist = None
+    if segs:
+        first = segs[min(segs)]
+        hist = ctx.torch.bincount(first.flatten().to(ctx.torch.int64), minlength=4).tolist()
+    return dict(value=n_cases * args.steps / elapsed, elapsed=elapsed, scaling="strong", dtype=dtype,
+                config={"workload": wl["name"], "patch": list(PATCH), "cases": n_cases, "cases_per_rank": len(mine),
+                        "tiles_in_batch": tiles, "mirrors": 8, "models": [m[0] for m in wl["models"]],
+                        "sharding": "cases round-robin over ranks, no data-path collective",
+                        "tflop_per_batch": round(flops_batch / 1e12, 2)},
+                sustained=flops_batch * args.steps / elapsed / 1e12 / ctx.world,
+                roofline=roofline_of(prof, dtype, traffic_ok=False), kernels=kernel_table(prof), label_histogram=hist)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    maybe_self_launch(args, argv)
+
+    import torch  # noqa: F401  (first GPU-capable import happens only here, after the self-launch decision)
+    from brats_amd import synthetic, preprocessing, ops
+
+    ctx = Ctx(args)
+    dtype = args.dtype or WORKLOADS[args.config]["dtype"]
+
+    if args.config == 4:
+        r = run_config4(ctx, args, dtype)
+        if ctx.rank == 0:
+            print(json.dumps({
+                "metric": "BraTS volumes/sec (4-modality 240x240x155)", "value": round(r["value"], 4), "unit": "volumes/s",
+                "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": r["scaling"],
+                "vs_baseline": None, "dtype": dtype, "data": "synthetic", "config": r["config"],
+                "sustained_tflops_per_gpu": round(r["sustained"], 2), "roofline": r["roofline"], "cpu_baseline": None,
+                "kernels": r["kernels"], "label_histogram": r["label_histogram"]}))
+        ctx.close()
+        return
+
+    raw = synthetic.make_volume(seed=1000 + ctx.rank)
+    data, props = preprocessing.preprocess_case(raw, ctx.device)
+    steps_tbl = [ops.compute_steps(PATCH[a], max(PATCH[a], data.shape[1 + a]), 0.5) for a in range(3)]
+    want_cpu = not args.no_cpu_baseline and ctx.world == 1
+    oracle = CpuOracle(first_tile(data, steps_tbl)) if (want_cpu and ctx.rank == 0) else None
+    cpu = None
+    if oracle is not None:
+        name, seed = WORKLOADS[args.config]["models"][0]
+        oracle.forward(name, seed, min_forwards=2, budget_s=10.0)  # >= 2 timed forwards, about 10 s of CPU work
+
+    main_res = run_single_volume(ctx, args, args.config, dtype, args.steps, args.warmup, data, props, steps_tbl, oracle)
+    flops_per_volume, elapsed = main_res.pop("_flops_per_volume"), main_res.pop("_elapsed")
+
+    secondary = None
+    if args.config == 2 and dtype == "f32" and ctx.world == 1 and not args.no_secondary and not args.batch_tiles:
+        # BASELINE.json configs[2] under the same clock and the same oracle tile (3 steps each), and the PCIe-inclusive leg
+        secondary = {}
+        for dt in ("f16", "f32"):
+            r = run_single_volume(ctx, args, 3, dt, 3, 1, data, props, steps_tbl, oracle)
+            r.pop("_flops_per_volume"); r.pop("_elapsed")
+            secondary[f"config3_{dt}"] = r
+        secondary["end_to_end"] = run_end_to_end(ctx, raw)
+
+    if ctx.rank != 0:
+        ctx.close()
+        return
+
+    if oracle is not None:
+        from brats_amd import network as _net
+        name, seed = WORKLOADS[args.config]["models"][0]
+        per_fw, n_fw = oracle.seconds[name]
+        sd, _ = synthetic.make_model(name, seed=seed)
+        flops_model0 = _net.topology_from_state_dict(sd).conv_flops(PATCH)
+        est_volume_s = per_fw * flops_per_volume / flops_model0
+        cfgd = main_res["config"]
+        cpu = dict(value=round(1.0 / est_volume_s, 6), unit="volumes/s", cores=oracle.cores, kind="port",
+                   sample=f"{n_fw} forwards of model {name} on the first 1x4x128^3 tile of the timed volume with the torch-CPU fp32 "
+                          f"oracle ({per_fw:.2f} s each), scaled by flops to the "
+                          f"{cfgd['tiles_per_volume'] * cfgd['mirrors'] * len(cfgd['models'])} forwards of one volume",
+                   seconds_per_volume_est=round(est_volume_s, 2))
+        if "B" in oracle.seconds:
+            cpu["model_B_forward_s"] = round(oracle.seconds["B"][0], 2)
+
     out = {
-        "metric": "BraTS volumes/sec (4-modality 240x240x155)", "value": round(value, 4), "unit": "volumes/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": workload, "patch": list(patch), "tiles_per_volume": n_tiles, "mirrors": n_mirrors,
-                   "models": [m[0] for m in models], "crop": list(data.shape[1:]), "sharding": "cases (one volume per rank per step)",
-                   "tflop_per_volume": round(flops_per_volume / 1e12, 3)},
-        "sustained_tflops_per_gpu": round(flops_per_volume * args.steps / elapsed / 1e12, 2),
-        "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_ref": parity, "kernels": kernels,
-        "label_histogram": label_hist,
-        "speedup_vs_nominal_5min": round(300.0 / (elapsed / args.steps), 1),
+        "metric": "BraTS volumes/sec (4-modality 240x240x155)", "value": main_res["volumes_per_s"], "unit": "volumes/s",
+        "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": main_res["config"], "sustained_tflops_per_gpu": main_res["sustained_tflops_per_gpu"],
+        "roofline": main_res["roofline"], "cpu_baseline": cpu, "parity_vs_cpu_ref": main_res.get("parity_vs_cpu_ref"),
+        "kernels": main_res["kernels"], "label_histogram": main_res["label_histogram"],
+        "speedup_vs_nominal_5min": main_res["speedup_vs_nominal_5min"],
     }
+    if secondary is not None:
+        out["secondary"] = secondary
     print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

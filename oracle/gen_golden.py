@@ -11,6 +11,8 @@ were made.  Weights and inputs come from frozen np.random.RandomState streams
   net_small_*.npz   full logits of tiny variants (nonlin_first etc.) used by fast CPU tests.
   driver_tables.npz label-round ensemble truth table produced by the reference's numpy
                     expression (run_brats2021_inference_singlethread.py:305).
+  rag_kb.json       config 5: the seven knowledge-base articles and, per query, what the reference's own
+                    DummyVectorStore / is_clinical_query return (see gen_rag_fixture).
 
     python -m oracle.gen_golden
 """
@@ -79,7 +81,74 @@ def main():
     a, b = np.meshgrid(np.arange(5, dtype=np.float64), np.arange(5, dtype=np.float64), indexing="ij")
     np.savez_compressed(os.path.join(OUT, "driver_tables.npz"),
                         label_round=np.round((a + b) / 2.0).astype(np.uint8))
+    gen_rag_fixture()
     print("wrote", sorted(os.listdir(OUT)))
+
+
+RAG_QUERIES = [
+    "What does midline shift mean in my report?", "Why is there edema around the tumor?", "what is an enhancing tumor",
+    "Which MRI sequences show the peritumoral swelling best", "How are tumor volumes measured in cubic centimeters",
+    "explain non-enhancing tumor core and necrosis", "what is a glioma", "T1ce contrast gadolinium enhancement",
+    "zzz qqq", "", "What treatment do I need for this glioma?", "is the prognosis bad given the midline shift",
+]
+
+
+def _import_by_path(name, path, stand_ins=None):
+    import importlib.util
+    import types
+    saved = {k: sys.modules.get(k) for k in (stand_ins or {})}
+    try:
+        for mod, attrs in (stand_ins or {}).items():
+            m = types.ModuleType(mod)
+            m.__dict__.update(attrs)
+            sys.modules[mod] = m
+        spec = importlib.util.spec_from_file_location(name, path)
+        module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(module)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return module
+
+
+def gen_rag_fixture():
+    """tests/golden/rag_kb.json - BASELINE.json configs[4]: the reference's OWN DummyVectorStore
+    (RAG_Assistant/rag_assistant.py:131-211, imported unmodified; numpy only) built over the seven knowledge_base
+    articles as the reference's own parse_md_file (RAG_Assistant/vector_store_builder.py:71-141, imported with inert
+    stand-ins for the absent chromadb package, which parse_md_file never touches) turns them into documents.  Stored:
+    the article files (input DATA of the knowledge base), and per query the gating decision, the top-2 document ids and
+    their float64 cosine scores."""
+    import glob
+    import hashlib
+    import json
+    ref = os.environ.get("REFERENCE_ROOT", "/root/reference")
+    rag = _import_by_path("_reference_rag_assistant", os.path.join(ref, "RAG_Assistant", "rag_assistant.py"))
+    vsb = _import_by_path("_reference_vector_store_builder", os.path.join(ref, "RAG_Assistant", "vector_store_builder.py"),
+                          {"chromadb": {"Collection": object}, "chromadb.utils": {"embedding_functions": object()}})
+    files = sorted(glob.glob(os.path.join(vsb.KNOWLEDGE_BASE_DIR, "*.md")))
+    docs, kb = [], {}
+    for path in files:
+        text, meta = vsb.parse_md_file(path)
+        kb[os.path.basename(path)] = open(path, "r", encoding="utf-8").read()
+        docs.append({"term": meta["title"], "text": text, "source": meta["source"]})
+    store = rag.DummyVectorStore(documents=docs)
+    expected = []
+    for q in RAG_QUERIES:
+        got = store.retrieve(q, top_k=2)
+        expected.append({"query": q, "clinical": bool(rag.is_clinical_query(q)),
+                         "top": [d["source"] for d, _ in got], "scores": [s for _, s in got],
+                         "all_scores": [float(v) for v in (store.vectors @ store._query_vector(q))]})
+    out = {"generator": "oracle/gen_golden.py:gen_rag_fixture (reference classes imported from /root/reference)",
+           "kb_files": kb,
+           "docs": [{"term": d["term"], "source": d["source"], "text_sha256": hashlib.sha256(d["text"].encode()).hexdigest()} for d in docs],
+           "vocab_size": len(store.vocab), "vocab_sha256": hashlib.sha256("\n".join(store.vocab).encode()).hexdigest(),
+           "expected": expected}
+    with open(os.path.join(OUT, "rag_kb.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False)
+    print("rag fixture:", len(docs), "docs,", len(store.vocab), "terms;", [(e["query"][:20], e["top"]) for e in expected[:3]])
 
 
 if __name__ == "__main__":

@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _write_case(amd, folder, case, shape_zyx, seed):
+def _write_case(amd, folder, case, shape_zyx, seed, zooms=(1.0, 1.0, 1.0)):
     vol = amd.synthetic.make_volume(seed=seed, shape=shape_zyx)
-    like = amd.nifti.make_header(shape_zyx[::-1], zooms=(1.0, 1.0, 1.0), origin=(0.0, -239.0, 0.0))
+    like = amd.nifti.make_header(shape_zyx[::-1], zooms=zooms, origin=(0.0, -239.0, 0.0))
     for c, mod in enumerate(("t1", "t1ce", "t2", "flair")):
         amd.nifti.save_like(folder / f"{case}_{mod}.nii.gz", np.ascontiguousarray(np.round(vol[c]).astype(np.int16).transpose(2, 1, 0)), like)
     raw = np.stack([amd.nifti.load(folder / f"{case}_{m}.nii.gz").as_zyx().astype(np.float32) for m in ("t1", "t1ce", "t2", "flair")])
@@ -71,6 +71,26 @@ def test_dropin_missing_models_exit_code(amd, gpu, tmp_path):
                           "--input", str(tmp_path / "in"), "--output", str(tmp_path / "out"),
                           "--results_folder", str(tmp_path / "none")], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert res.returncode == 1 and "[ERROR] Model not found" in res.stdout
+
+
+def test_dropin_refuses_a_grid_the_plans_would_resample(amd, gpu, tmp_path):
+    """a 2 mm input (e.g. an api.py upload) must not be segmented silently on the wrong grid.  The reference's
+    trainer.preprocess_patient would resample it to the plans' 1 mm spacing; resampling is not built, so the drop-in
+    fails loudly (non-zero exit -> run_full_pipeline.py:187-188 raises) instead of writing wrong labels / volumes."""
+    patch = (32, 32, 32)
+    results = tmp_path / "nnUNet_results"
+    base = results / "3d_fullres" / "Task500_BraTS2021"
+    plans = amd.checkpoint.default_brats_plans(patch)
+    for name, preset, seed in ((amd.driver.MODEL1, "A", 40), (amd.driver.MODEL2, "B", 50)):
+        amd.checkpoint.save_model_folder(base / name, name.split("__")[0], [amd.synthetic.make_model(preset, seed=seed, num_pool=2, max_feat=64)[0]], plans)
+    case_dir = tmp_path / "case2mm"
+    case_dir.mkdir()
+    _write_case(amd, case_dir, "BraTS-GLI-00009-000", (40, 56, 48), seed=79, zooms=(2.0, 2.0, 2.0))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "run_brats2021_inference_singlethread.py"), "--input", str(case_dir),
+                          "--output", str(tmp_path / "out"), "--results_folder", str(results), "--folds", "0"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0 and "resampling is not implemented" in (res.stdout + res.stderr)
+    assert not (tmp_path / "out" / "BraTS-GLI-00009-000.nii.gz").exists()
 
 
 def test_nnunet_predict_cli_save_npz_and_probability_ensemble(amd, gpu, tmp_path):

@@ -58,6 +58,26 @@ def test_evaluator_matches_reference_formulas(amd, gpu):
         amd.evaluate.confusion(torch.from_numpy(gt).to(gpu), torch.from_numpy(gt[:10]).to(gpu))
 
 
+def test_out_of_range_labels_never_alias_a_real_label(amd, gpu):
+    """labels beyond the evaluated range go to an explicit "other" bin - the reference compares ``== label``
+    (evaluate_segmentation.py:20-21) and counts ``img == 3`` only in the ET threshold."""
+    rs = np.random.RandomState(5)
+    gt = rs.choice([0, 1, 2, 3, 4, 7, 200], size=(40, 50, 60), p=[0.6, 0.1, 0.1, 0.1, 0.05, 0.03, 0.02]).astype(np.uint8)
+    pred = gt.copy()
+    flip = rs.uniform(size=gt.shape) < 0.1
+    pred[flip] = rs.choice([0, 1, 2, 3, 4, 9, 255], size=int(flip.sum())).astype(np.uint8)
+    res = amd.evaluate.evaluate(torch.from_numpy(pred).to(gpu), torch.from_numpy(gt).to(gpu))
+    for lab in (1, 2, 3):
+        want = extras_ref.calculate_metrics(pred, gt, lab)
+        for k in ("tp", "fp", "fn", "tn", "dice", "specificity"):
+            assert res[lab][k] == pytest.approx(want[k], rel=1e-12, abs=1e-12), (lab, k)
+    cm = amd.evaluate.confusion(torch.from_numpy(pred).to(gpu), torch.from_numpy(gt).to(gpu), 6)
+    assert cm.sum() == gt.size and cm[5].sum() == int((pred >= 5).sum()) and cm[:, 5].sum() == int((gt >= 5).sum())
+    seg = gt.copy()
+    _, n3 = amd.evaluate.apply_brats_threshold(torch.from_numpy(seg).to(gpu), 10 ** 9, 2)
+    assert n3 == int((seg == 3).sum())          # labels 4, 7, 200 are not ET voxels
+
+
 DOCS = [{"term": "glioma", "text": "A glioma is a tumour that starts in the glial cells of the brain or spine."},
         {"term": "edema", "text": "Peritumoral edema is swelling around a tumour caused by fluid accumulation."},
         {"term": "necrosis", "text": "Necrotic core refers to dead tissue in the centre of the tumour."},

@@ -14,11 +14,15 @@ pytestmark = pytest.mark.gpu
 PROB_TOL = 1e-3
 
 
-def _check_logits(got, ref):
+LOGIT_REL_TOL = 2e-4   # x logit spread; tightened to the measured level below once r02 numbers are in
+
+
+def _check_logits(got, ref, what=""):
     spread = float(ref.std())
     err = float(np.abs(got - ref).max())
     perr = float(np.abs(1 / (1 + np.exp(-got.astype(np.float64))) - 1 / (1 + np.exp(-ref.astype(np.float64)))).max())
-    assert err <= 2e-4 * max(spread, 1.0), f"logit max abs err {err} (spread {spread})"
+    print(f"PARITY {what}: logit max abs err {err:.3e} = {err / max(spread, 1.0):.2e} x spread ({spread:.2f}), prob err {perr:.2e}")
+    assert err <= LOGIT_REL_TOL * max(spread, 1.0), f"logit max abs err {err} (spread {spread})"
     assert perr <= PROB_TOL, f"sigmoid prob err {perr}"
 
 
@@ -29,7 +33,7 @@ def test_forward_64_matches_oracle(amd, gpu, name):
     x = np.random.RandomState(1).standard_normal((1, 4, 64, 64, 64)).astype(np.float32)
     ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])).numpy()
     got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
-    _check_logits(got, ref)
+    _check_logits(got, ref, f"64^3 {name}")
     net.close()
 
 
@@ -138,7 +142,7 @@ def test_fold_mean_and_tile_sharding(amd, gpu):
 # >= 0.999 on the voxels whose reference logit is not within 1.0 of the decision threshold
 # (measured: 0.5 % of the spread for BatchNorm-folded nets, 2.3 % with run-time Instance/GroupNorm,
 # which rounds twice per block).
-def _check_logits_f16(got, ref):
+def _check_logits_f16(got, ref, dice_all=0.995):
     spread = float(ref.std())
     err = float(np.abs(got - ref).max())
     assert err <= 3e-2 * max(spread, 1.0), f"fp16 logit max abs err {err} (spread {spread})"
@@ -146,7 +150,9 @@ def _check_logits_f16(got, ref):
     pr = 1 / (1 + np.exp(-ref.astype(np.float64)))
     assert float(np.abs(pg - pr).max()) <= 0.1
     lg, lr = tiler_ref.regions_to_labels(pg[0].astype(np.float32)), tiler_ref.regions_to_labels(pr[0].astype(np.float32))
-    assert tiler_ref.brats_region_dice(lg, lr)["mean"] >= 0.995
+    d_all = tiler_ref.brats_region_dice(lg, lr)["mean"]
+    print(f"PARITY f16: logit err {err / max(spread, 1.0):.2e} x spread, prob err {float(np.abs(pg - pr).max()):.3f}, Dice {d_all:.6f}")
+    assert d_all >= dice_all
     sure = (np.abs(ref[0]) >= 1.0).all(0)
     assert tiler_ref.brats_region_dice(lg[sure], lr[sure])["mean"] >= 0.999
     return err / spread
@@ -254,3 +260,57 @@ def test_full_size_config3_f16_agrees_with_f32(amd, gpu):
     d = tiler_ref.brats_region_dice(segs["f16"], segs["f32"])
     assert d["mean"] >= 0.999, d
     assert set(np.unique(segs["f16"])) <= {0, 1, 2, 3}
+
+
+# --------------------------------------------------------------------------- the reference's real setting at full size
+# run_brats2021_inference_singlethread.py:208-211 (do_tta=True) and :263-264 (both ensemble members): one full 128^3
+# tile against the CPU oracle for model B (GroupNorm-16, encoder_scale=2, 3.34 TFLOP per forward) in fp32 and fp16, and
+# the 8-way mirror TTA of one tile through the sliding-window entry point for models A and B.
+@pytest.fixture(scope="module")
+def tile128():
+    return np.random.RandomState(2).standard_normal((1, 4, 128, 128, 128)).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def oracle_b_128(amd, tile128):
+    sd, meta = amd.synthetic.make_model("B", seed=8)
+    ref = unet_ref.unet_forward(sd, tile128, unet_ref.default_cfg(norm="group", num_groups=16)).numpy()
+    return sd, ref
+
+
+def test_forward_128_model_b_f32(amd, gpu, tile128, oracle_b_128):
+    sd, ref = oracle_b_128
+    net = amd.UNet(sd, norm="group", num_groups=16)
+    got = net(torch.from_numpy(tile128).to(gpu)).cpu().numpy()
+    _check_logits(got, ref, "128^3 B f32")
+    d = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(1 / (1 + np.exp(-got[0]))), tiler_ref.regions_to_labels(1 / (1 + np.exp(-ref[0]))))
+    assert d["mean"] >= 0.999
+    net.close()
+
+
+def test_forward_128_model_b_f16(amd, gpu, tile128, oracle_b_128):
+    """fp16 storage at the size the reference runs: the north_star gate (Dice >= 0.999 against the CPU path)."""
+    sd, ref = oracle_b_128
+    net = amd.UNet(sd, norm="group", num_groups=16, dtype="f16")
+    got = net(torch.from_numpy(tile128).to(gpu)).cpu().numpy()
+    rel = _check_logits_f16(got, ref, dice_all=0.999)
+    print(f"PARITY 128^3 B f16: max logit err / spread = {rel:.2e}")
+    net.close()
+
+
+@pytest.mark.parametrize("name,seed", [("A", 7), ("B", 8)])
+def test_tta_full_tile_matches_oracle(amd, gpu, tile128, name, seed):
+    """8 mirrored forwards of one 128^3 volume (= one tile, so no Gaussian: nnU-Net's single-tile case), summed with
+    weight 1/8 after flipping back, against tiler_ref.mirror_and_predict on the CPU (8 x 4 s / 8 x 10 s of oracle)."""
+    sd, meta = amd.synthetic.make_model(name, seed=seed)
+    cfg = unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])
+    net_fn = tiler_ref.make_net_fn(sd, cfg)
+    ref = tiler_ref.mirror_and_predict(net_fn, torch.from_numpy(tile128), (0, 1, 2), True, "sigmoid", None)[0].numpy()
+    for dtype, tol, dice_min in (("f32", PROB_TOL, 0.999), ("f16", 5e-2, 0.999)):
+        net = amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"], dtype=dtype)
+        got = amd.predictor.predict_folds([net], tile128[0], (128, 128, 128), 0.5, True, (0, 1, 2), True, "sigmoid").cpu().numpy()
+        err = float(np.abs(got - ref).max())
+        d = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(got), tiler_ref.regions_to_labels(ref))
+        print(f"PARITY TTA 128^3 {name} {dtype}: prob err {err:.2e}, Dice {d['mean']:.6f}")
+        assert err <= tol and d["mean"] >= dice_min
+        net.close()

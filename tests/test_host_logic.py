@@ -104,3 +104,54 @@ def test_oracle_kaist_postprocessing_truth_table():
     conv = driver_ref.convert_labels_back_to_brats(seg)
     assert np.array_equal(conv, extras_ref.convert_labels(seg, "brats2021"))       # the in-repo converter pins it
     assert set(np.unique(conv)) == {0, 1, 2, 4} and (conv == 4).sum() == 3 and (conv == 2).sum() == 4 and (conv == 1).sum() == 2
+
+
+def test_knowledge_base_loader_and_gating_match_the_reference_fixture(amd, tmp_path):
+    """BASELINE.json configs[4], host side: the seven knowledge-base articles parsed by the product give the documents,
+    vocabulary and question gating the reference's own code gave (tests/golden/rag_kb.json, made by oracle/gen_golden.py
+    from the reference's DummyVectorStore / parse_md_file / is_clinical_query)."""
+    import hashlib
+    import json
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "rag_kb.json"), encoding="utf-8"))
+    for name, text in fx["kb_files"].items():
+        (tmp_path / name).write_text(text, encoding="utf-8")
+    docs = amd.retrieval.load_knowledge_base(tmp_path)
+    assert [d["source"] for d in docs] == [d["source"] for d in fx["docs"]]
+    assert [d["term"] for d in docs] == [d["term"] for d in fx["docs"]]
+    assert [hashlib.sha256(d["text"].encode()).hexdigest() for d in docs] == [d["text_sha256"] for d in fx["docs"]]
+    store = amd.retrieval.DummyVectorStore(docs)          # index built on the host; nothing touches the device yet
+    assert len(store.vocab) == fx["vocab_size"]
+    assert hashlib.sha256("\n".join(store.vocab).encode()).hexdigest() == fx["vocab_sha256"]
+    for e in fx["expected"]:
+        assert amd.retrieval.is_clinical_query(e["query"]) == e["clinical"], e["query"]
+        assert np.allclose(store.vectors @ store._query_vector(e["query"]), e["all_scores"], atol=1e-15)
+    with pytest.raises(FileNotFoundError):
+        amd.retrieval.load_knowledge_base(tmp_path / "empty")
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """bench.py --gpus N without a launcher starts torch.distributed.run as a CHILD (never exec) before importing torch,
+    with the exact command line the driver uses, and relays its exit code."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"], port=29511)
+    assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+                       "--master-port", "29511", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3"]
+    calls = []
+
+    class Done:
+        returncode = 7
+    monkeypatch.setattr(bench.subprocess, "run", lambda c, env=None: calls.append((c, env)) or Done())
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = bench.parse_args(["--gpus", "2", "--config", "4"])
+    with pytest.raises(SystemExit) as e:
+        bench.maybe_self_launch(args, ["--gpus", "2", "--config", "4"])
+    assert e.value.code == 7 and calls and calls[0][0][-4:] == ["--gpus", "2", "--config", "4"]
+    assert calls[0][1]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    calls.clear()
+    monkeypatch.setenv("WORLD_SIZE", "2")                                  # already under a launcher: nothing is started
+    bench.maybe_self_launch(args, ["--gpus", "2"])
+    bench.maybe_self_launch(bench.parse_args([]), [])                      # N = 1: nothing is started
+    assert not calls
