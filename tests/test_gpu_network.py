@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 PROB_TOL = 1e-3
 
 
-LOGIT_REL_TOL = 2e-4   # x logit spread; tightened to the measured level below once r02 numbers are in
+LOGIT_REL_TOL = 6e-5   # x logit spread.  Measured on MI355X (round 2): 0.7-4.7e-5 over every fp32 case of this file
+                       # (worst: InstanceNorm 64^3 4.65e-5; the Winograd F(2x2,3x3) path at 128^3 3.8e-5), so a
+                       # regression of the Winograd numerics by 1.6x already fails
 
 
 def _check_logits(got, ref, what=""):
@@ -135,20 +137,19 @@ def test_fold_mean_and_tile_sharding(amd, gpu):
 
 
 # --------------------------------------------------------------------------- fp16 storage (BASELINE configs[2])
-# Tolerance for the fp16 path, stated here as the north_star asks: activations are rounded to fp16
-# (2^-11 relative) after every block, accumulation stays fp32.  Against the fp32 CPU oracle we require
-# logits within 3 % of their spread, probabilities within 0.1 (= the sigmoid's slope 1/4 times the logit bound at
-# the synthetic nets' spread; a probability error only matters next to the threshold, which the Dice checks cover), Dice >= 0.995 on all voxels and
-# >= 0.999 on the voxels whose reference logit is not within 1.0 of the decision threshold
-# (measured: 0.5 % of the spread for BatchNorm-folded nets, 2.3 % with run-time Instance/GroupNorm,
-# which rounds twice per block).
-def _check_logits_f16(got, ref, dice_all=0.995):
+# Tolerance for the fp16 path, stated here as the north_star asks: activations are rounded to fp16 (2^-11 relative)
+# after every block, accumulation stays fp32.  Against the fp32 CPU oracle we require the north_star's gate, Dice >= 0.999
+# of the label maps on ALL voxels, logits within 3 % of their spread and probabilities within 0.05 (0.08 for the one case
+# below whose InstanceNorm statistics at the bottleneck are taken over 2^3 = 8 voxels, which amplifies any perturbation;
+# the reference's 128^3 patches have 64).  Measured on MI355X (round 2): logits 0.5-2.1 % of the spread, probabilities
+# 0.016-0.063, Dice 0.99943-0.99976; with 8-way TTA at 128^3 probabilities 3.8e-3 / 4.5e-3, Dice 0.99984 / 0.99959.
+def _check_logits_f16(got, ref, dice_all=0.999, prob_tol=0.05):
     spread = float(ref.std())
     err = float(np.abs(got - ref).max())
     assert err <= 3e-2 * max(spread, 1.0), f"fp16 logit max abs err {err} (spread {spread})"
     pg = 1 / (1 + np.exp(-got.astype(np.float64)))
     pr = 1 / (1 + np.exp(-ref.astype(np.float64)))
-    assert float(np.abs(pg - pr).max()) <= 0.1
+    assert float(np.abs(pg - pr).max()) <= prob_tol
     lg, lr = tiler_ref.regions_to_labels(pg[0].astype(np.float32)), tiler_ref.regions_to_labels(pr[0].astype(np.float32))
     d_all = tiler_ref.brats_region_dice(lg, lr)["mean"]
     print(f"PARITY f16: logit err {err / max(spread, 1.0):.2e} x spread, prob err {float(np.abs(pg - pr).max()):.3f}, Dice {d_all:.6f}")
@@ -165,7 +166,7 @@ def test_forward_f16_64_matches_oracle(amd, gpu, name):
     x = np.random.RandomState(1).standard_normal((1, 4, 64, 64, 64)).astype(np.float32)
     ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])).numpy()
     got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
-    rel = _check_logits_f16(got, ref)
+    rel = _check_logits_f16(got, ref, prob_tol=0.08 if name == "A_in" else 0.05)
     print(f"fp16 {name}: max logit err / spread = {rel:.2e}")
     net.close()
 
@@ -189,7 +190,7 @@ def test_sliding_window_f16_tta(amd, gpu):
     got = amd.predictor.predict_folds([net], vol, patch).cpu().numpy()
     assert np.abs(got - ref).max() <= 5e-2
     d = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(got), tiler_ref.regions_to_labels(ref))
-    assert d["mean"] >= 0.995
+    assert d["mean"] >= 0.999
 
 
 # --------------------------------------------------------------------------- full BASELINE size
@@ -239,9 +240,10 @@ def test_full_size_config2_properties_and_oracle_tiles(amd, gpu):
 
 
 def test_full_size_config3_f16_agrees_with_f32(amd, gpu):
-    """BASELINE.json configs[2] at full size (8-way mirror TTA, models A + B, label-round ensemble) in fp16 storage against
-    the fp32 path of the same library - the fp32 path is the one pinned to the CPU oracle tile by tile above, so this
-    carries the oracle's verdict to the full-size fp16 configuration: Dice of the ensembled label maps >= 0.999."""
+    """BASELINE.json configs[2] at full size (8-way mirror TTA, models A + B, label-round ensemble): a CONSISTENCY check of
+    the fp16 path against the fp32 path of the same library over all 8 tiles (Dice of the ensembled label maps >= 0.999).
+    The oracle's own verdict on this configuration is test_tta_full_tile_matches_oracle / test_forward_128_model_b_* below
+    (one full 128^3 tile per model, fp32 and fp16, against the CPU oracle)."""
     raw = amd.synthetic.make_volume(seed=1001)
     data, props = amd.preprocessing.preprocess_case(raw)
     lo = [b[0] for b in props["crop_bbox"]]
@@ -306,7 +308,7 @@ def test_tta_full_tile_matches_oracle(amd, gpu, tile128, name, seed):
     cfg = unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])
     net_fn = tiler_ref.make_net_fn(sd, cfg)
     ref = tiler_ref.mirror_and_predict(net_fn, torch.from_numpy(tile128), (0, 1, 2), True, "sigmoid", None)[0].numpy()
-    for dtype, tol, dice_min in (("f32", PROB_TOL, 0.999), ("f16", 5e-2, 0.999)):
+    for dtype, tol, dice_min in (("f32", 1e-4, 0.9999), ("f16", 2e-2, 0.999)):
         net = amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"], dtype=dtype)
         got = amd.predictor.predict_folds([net], tile128[0], (128, 128, 128), 0.5, True, (0, 1, 2), True, "sigmoid").cpu().numpy()
         err = float(np.abs(got - ref).max())
