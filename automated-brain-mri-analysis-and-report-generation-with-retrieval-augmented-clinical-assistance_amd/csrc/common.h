@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <type_traits>
 
 #include "../../include/mi355_nnunet.h"
 
@@ -79,6 +80,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N).  Indices are constant EXPRESSIONS inside the body
+// (inline-asm immediates, register-array subscripts), whatever the optimiser decides about a "#pragma unroll" loop.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 
 inline int ilog2_exact(int v) {

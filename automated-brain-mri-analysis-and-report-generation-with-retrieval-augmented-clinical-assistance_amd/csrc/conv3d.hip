@@ -192,6 +192,66 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
     }
 }
 
+// Whole-line variant of the plain epilogue (no statistics, no fused head).  In the accumulator layout a lane holds 16
+// couts of ONE voxel, so a 16-B store instruction touches 32 different 128-B lines, a quarter of each: the store tail of
+// a 4x4x32x32 tile took 13.7k cycles of a workgroup's time (tools/wino2_probe.hip stamps, round 2) - issue-bound on
+// partial lines, not bandwidth-bound.  Here each 32-voxel x 32-cout fragment is transposed through LDS (a wave-private
+// 32 x 36-float image: ds_write_b128 by voxel row, ds_read_b128 by line) so that 8 consecutive lanes store one whole
+// 128-B line and an instruction covers 8 full lines; bias and LeakyReLU are applied after the transposition (one bias
+// quad per lane and cout block).  LDS traffic is free next to the f32 MFMAs (tools/coissue_probe.hip), VALU work is
+// the same as before.  `stage` = this wave's 32 * 36 floats; DS operations of one wave execute in order, so no barrier
+// is needed between the writes and the reads.
+constexpr int EPI_PITCH = 36;                      // floats per staged voxel row: 128 B + 16 B keeps ds_write_b128 conflict-free
+constexpr int EPI_STAGE_FLOATS = 32 * EPI_PITCH;   // per wave
+template <int MF, int NF>
+__device__ __forceinline__ void conv_epilogue_lines(f32x16 (&acc)[MF][NF], const ConvArgs &p, int n, int oz0, int oy0,
+                                                    int ox0, int co_blk, float *stage) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
+    const float slope = p.act == ACT_LRELU ? p.slope : 1.0f;
+    const f32x2 slope2 = {slope, slope};
+    const int srow = lane >> 3, spiece = lane & 7;
+    float *wr = stage + l31 * EPI_PITCH + 4 * half;
+    const float *rd = stage + srow * EPI_PITCH + spiece * 4;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        const f32x4 bias = *(const f32x4 *)(p.bias + co_blk + nf * 32 + spiece * 4);
+        const f32x2 b01 = {bias[0], bias[1]}, b23 = {bias[2], bias[3]};
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 raw = {acc[mf][nf][4 * g], acc[mf][nf][4 * g + 1], acc[mf][nf][4 * g + 2], acc[mf][nf][4 * g + 3]};
+                *(f32x4 *)(wr + 8 * g) = raw;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 raw = *(const f32x4 *)(rd + 8 * t * EPI_PITCH);
+                const int v = (wave * MF + mf) * 32 + 8 * t + srow;
+                const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
+                const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
+                f32x2 x0 = {raw[0], raw[1]}, x1 = {raw[2], raw[3]}, y0, y1;
+                f32x4 val;
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(x0) : "v"(x0), "v"(b01));
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(x1) : "v"(x1), "v"(b23));
+                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y0) : "v"(x0), "v"(slope2));
+                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y1) : "v"(x1), "v"(slope2));
+                asm("v_max_f32 %0, %1, %2" : "=v"(val[0]) : "v"(x0[0]), "v"(y0[0]));  // bare max: fmaxf would add a
+                asm("v_max_f32 %0, %1, %2" : "=v"(val[1]) : "v"(x0[1]), "v"(y0[1]));  // canonicalising max per value
+                asm("v_max_f32 %0, %1, %2" : "=v"(val[2]) : "v"(x1[0]), "v"(y1[0]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(val[3]) : "v"(x1[1]), "v"(y1[1]));
+#ifdef MI355_W2_ABL_NOSTORE
+                asm volatile("" :: "v"(val), "v"(ok), "v"(oz), "v"(oy), "v"(ox));
+#else
+                if (ok)
+                    *(f32x4 *)(p.out + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + nf * 32 + spiece * 4) = val;
+#endif
+            }
+        }
+    }
+}
+
 template <int STRIDE, int CC, int MF, int NF>
 __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -778,10 +838,29 @@ struct Wino2Args {
     const float *zeros;  // >= 16 B of zeros in global memory: the source of every out-of-volume piece
 };
 
+#ifdef MI355_W2_STAMPS
+// Diagnostic build only (tools/wino2_probe.hip): per-workgroup cycle sums of the kernel's phases, wave 0, via s_memtime.
+// Slots: 0 = chunk prologue, 1 = step loop, 2 = chunk-end drain + barrier, 3 = output transform, 4 = shared epilogue,
+// 5 = whole kernel, 6 = chunks, 7 = tiles, 8 = barrier after the epilogue, 9 = accumulator reset + tile set-up.  The shipped kernel contains no stamp.
+__device__ unsigned long long w2_stamps[1024 * 16];
+#define W2_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define W2_ACC(slot, a, b) do { if (threadIdx.x == 0) w2_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] += (b) - (a); } while (0)
+#define W2_CNT(slot) do { if (threadIdx.x == 0) w2_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] += 1; } while (0)
+#else
+#define W2_T(var)
+#define W2_ACC(slot, a, b)
+#define W2_CNT(slot)
+#endif
+
 constexpr int W2_IX = 34, W2_IY = 6, W2_IZ = 6, W2_BV = W2_IX * W2_IY * W2_IZ;  // 1224 brick voxels
 constexpr int W2_BUF_FLOATS = (4 * W2_BV + 56) * 4;  // 4 quad planes + the overrun of the last DMA range
 constexpr size_t W2_LDS_BYTES = (size_t)(2 * W2_BUF_FLOATS + 4 * 32 * 2) * sizeof(float);
 
+// PLAIN = bias + LeakyReLU + store only (BatchNorm-folded / un-normalised layers): the whole-line epilogue below, and no
+// code for statistics or the fused head in the instantiation - their register demand made the allocator spill loop
+// invariants at kernel entry, and the epilogue's reloads missed every cache level after a chunk of streaming DMA traffic
+// (9-11k cycles per tile, tools/wino2_probe.hip stamps, round 2).
+template <bool PLAIN>
 __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -791,7 +870,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
     constexpr int STEPS = 12;      // (quad 0..3) x (dx 0..2) per 16-channel chunk
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
     const int half = lane >> 5;
     const int l31 = lane & 31;
     const int bz = wave >> 1, by = wave & 1;
@@ -842,7 +921,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
         // wave-uniform part (SALU); the per-lane part fits 32 bits (host check)
         src += ((((size_t)tc.n * p.Di + (tc.oz0 - 1)) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1)) * (long)Csrc + coff;
-        const unsigned pk = dma_pk[k];
+        unsigned pk = dma_pk[k];
+        asm volatile("" : "+v"(pk));  // unpack HERE, every time: hoisted out of the tile loop the unpacked fields and the 64-bit
+                                      // offsets built from them are ~40 registers that get spilled to scratch at kernel entry
         const int rz = pk & 15, ry = (pk >> 4) & 15, bx = (pk >> 8) & 255, over = pk >> 16;
         const bool in_vol = ((unsigned)(tc.oz0 - 1 + rz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + ry) < (unsigned)p.Hi) &&
                             ((unsigned)(tc.ox0 - 1 + bx) < (unsigned)p.Wi);
@@ -883,15 +964,23 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                  :                                                                                                     \
                  : "memory")
 
+#ifdef MI355_W2_STAGGER
+    {   // experiment: desynchronise the workgroups so that their store bursts do not coincide
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)(((int)blockIdx.x >> 3) & 7) * (MI355_W2_STAGGER);
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+    W2_T(t_kernel0);
     TileCoord cur = decode(tile);
 #pragma unroll
     for (int k = 0; k < 5; ++k) dma_group(cur, 0, k, lds);
     f32x4 uq[2][8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (k < 4) W2_ULOAD(uq[0][k], wl0, wblk, (k & 3) * 1024);
-        else W2_ULOAD(uq[0][k], wl1, wblk, (k & 3) * 1024);
-    }
+    static_for<0, 8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        auto &u0 = uq[0]; const unsigned wl = k < 4 ? wl0 : wl1; const float *wb = wblk;  // (named: asm operands alone do not capture)
+        W2_ULOAD(u0[k], wl, wb, (k & 3) * 1024);
+    });
     __syncthreads();
 
     // rows of step `st` (16 x ds_read_b64) / the two halves of the transform V = B^T D B (first along y within each z
@@ -919,6 +1008,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
     // tile loop outside, chunk loop inside, accumulators scoped to one tile: a conditional reset inside a single
     // flattened loop makes the register allocator spill the 256 accumulators at every back edge
     for (; tile < hi; tile += nl) {
+        W2_T(t_t0);
         f32x16 acc[16];
 #pragma unroll
         for (int f = 0; f < 16; ++f)
@@ -927,6 +1017,12 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
         const int ntile = tile + nl;
         const TileCoord nxt_tile = ntile < hi ? decode(ntile) : cur;
 
+#ifdef MI355_W2_STAMPS
+#pragma unroll
+        for (int f = 0; f < 16; ++f) asm volatile("" : "+a"(acc[f]));
+#endif
+        W2_T(t_t1);
+        W2_ACC(9, t_t0, t_t1);
         for (int ch = 0; ch < p.nchunks; ++ch) {
             const bool last_ch = ch == p.nchunks - 1;
             const bool have_next = !last_ch || ntile < hi;
@@ -939,6 +1035,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
             const float *wnx = wblk + (size_t)nch_eff * (STEPS * 16 * 128);
 
             // chunk prologue (exposed once per chunk): V of step 0, rows of step 1
+            W2_T(t_c0);
             f32x2 d[16], T[16], V[2][16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) d[k] = row_read(bufc, 0, k);
@@ -949,74 +1046,186 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) d[k] = row_read(bufc, 1, k);
             __builtin_amdgcn_sched_barrier(0);
+            W2_T(t_c1);
+            W2_ACC(0, t_c0, t_c1);
 
             // One step = 32 MFMAs (64 cycles each); everything else of the pipeline is dealt out between them, one
             // scheduling fence per MFMA: the transform of step st+1 (its rows were read during step st-1), the weight
             // loads of step st+1, the row reads of step st+2 and, on even steps, 4 brick DMAs of the next chunk.
-#pragma unroll
-            for (int st = 0; st < STEPS; ++st) {
-                const int pp = st & 1;
+            static_for<0, STEPS>([&](auto st_c) {
+                constexpr int st = decltype(st_c)::value;
+                constexpr int pp = st & 1;
                 // this step's weights: everything older than the 4 brick DMAs of the previous step must have landed
                 // (the DMAs were issued after the weight loads and may stay in flight: they get a step and a half)
-                if (st > 0 && ((st - 1) & 1) == 0 && st - 1 < 10) W2_UWAIT(uq[pp], 4);
-                else W2_UWAIT(uq[pp], 0);
+                auto &uc = uq[pp];
+                if constexpr (st > 0 && ((st - 1) & 1) == 0 && st - 1 < 10) W2_UWAIT(uc, 4);
+                else W2_UWAIT(uc, 0);
                 const float *wn = (st + 1 < STEPS) ? wch + (size_t)(st + 1) * (16 * 128) : wnx;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const int f = i & 15, j = i >> 4;
+                static_for<0, 32>([&](auto i_c) {
+                    constexpr int i = decltype(i_c)::value;
+                    constexpr int f = i & 15, j = i >> 4;
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(uq[pp][f >> 1][(f & 1) * 2 + j], V[pp][f][j], acc[f], 0, 0, 0);
-                    if (st + 1 < STEPS) {
-                        if (i < 8) { t_op(d, T, 2 * i); t_op(d, T, 2 * i + 1); }
-                        else if (i >= 16) v_op(T, V[pp ^ 1], i - 16);
+                    // the transform of step st+1 in four bunches of eight packed adds: a gap that holds any VALU work costs
+                    // the matrix pipe ~5 cycles plus ~4.4 per instruction (tools/coissue_probe.hip), so 32 adds dealt one
+                    // per gap cost twice what they cost in four gaps
+                    if constexpr (st + 1 < STEPS && (i == 0 || i == 2)) {
+                        static_for<0, 8>([&](auto u) { t_op(d, T, 4 * i + decltype(u)::value); });
+                    } else if constexpr (st + 1 < STEPS && (i == 16 || i == 18)) {
+                        static_for<0, 8>([&](auto u) { v_op(T, V[pp ^ 1], 4 * (i - 16) + decltype(u)::value); });
                     }
-                    if (i < 16 && (i & 1) == 0) {
-                        const int k = i >> 1;
-                        if (k < 4) W2_ULOAD(uq[pp ^ 1][k], wl0, wn, (k & 3) * 1024);
-                        else W2_ULOAD(uq[pp ^ 1][k], wl1, wn, (k & 3) * 1024);
+                    // (the last step of a tile's last chunk fetches nothing: the next tile's first fragments are loaded
+                    //  behind the epilogue, so that they are not 32 live registers across it)
+                    if constexpr (i < 16 && (i & 1) == 0) {
+                        constexpr int k = i >> 1;
+                        auto &un = uq[pp ^ 1]; const unsigned wl = k < 4 ? wl0 : wl1; const float *wb = wn;
+                        if (st + 1 < STEPS || !last_ch) W2_ULOAD(un[k], wl, wb, (k & 3) * 1024);
                     }
-                    if (st + 2 < STEPS && i >= 8 && i < 16) {  // two rows per group (one ds_read2_b64), right after the
-                        d[2 * (i - 8)] = row_read(bufc, st + 2, 2 * (i - 8));          // T ops released d: the data is
+                    if constexpr (st + 2 < STEPS && i >= 8 && i < 16) {  // two rows per group (one ds_read2_b64), right after
+                        d[2 * (i - 8)] = row_read(bufc, st + 2, 2 * (i - 8));          // the T ops released d: the data is
                         d[2 * (i - 8) + 1] = row_read(bufc, st + 2, 2 * (i - 8) + 1);  // needed 16 MFMAs later
                     }
-                    if ((st & 1) == 0 && st < 10 && i == 16) dma_group(nxt, nch_eff, st >> 1, bufn);
+                    if constexpr ((st & 1) == 0 && st < 10 && i == 20) dma_group(nxt, nch_eff, st >> 1, bufn);
                     __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+                });
+            });
+            W2_T(t_c2);
+            W2_ACC(1, t_c1, t_c2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier
             __syncthreads();  // retires this chunk's DMA (vmcnt(0)) and orders it before the next chunk's ds_reads
             buf ^= 1;
+            W2_T(t_c3);
+            W2_ACC(2, t_c2, t_c3);
+            W2_CNT(6);
         }
-        W2_UWAIT(uq[0], 0);  // the next tile's first fragments are in flight: settle them before the epilogue may spill them
+        W2_T(t_e0);
 
         // Y = A^T M A: along y within each z component, then along z; rows ordered mf = 2*zrow + yrow (packed over
         // accumulator register pairs: the epilogue is pure VALU time on a SIMD that has nothing else to run)
-        f32x16 out[4][1];
+        if constexpr (PLAIN) {
+            // Whole-line stores (see conv_epilogue_lines) through the brick buffer that has just been consumed - the other
+            // one already holds the next tile's first chunk.  The output transform streams straight into the wave's LDS
+            // image [fragment mf][voxel][cout] (8-B writes of two adjacent couts), so the 64 output values never exist
+            // as registers; the image is read back by 128-B lines.  One wave alone on its SIMD issues an instruction
+            // every 4-5 cycles, so the store phase is written for instruction count: the (z, y) row of a fragment is
+            // wave-uniform (scalar address and bounds), the lane's part of the address is one 32-bit offset per tile,
+            // the x bound one compare per 8-voxel group.
+            // (lane-derived values are rebuilt from the hardware lane id here: as loop invariants of the tile loop they were
+            //  hoisted to the kernel entry, spilled, and reloaded from scratch in this epilogue - six dependent round trips
+            //  to memory per tile)
+            int lane_e;  // volatile: the mbcnt pair is pure and would be hoisted (and spilled) like everything else
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+            float *stage = lds + (buf ^ 1) * W2_BUF_FLOATS + wave * (4 * EPI_STAGE_FLOATS);
+            float *wr = stage + (lane_e & 31) * EPI_PITCH + 4 * (lane_e >> 5);
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            f32x2 P[4][2];
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 P[4][2];
 #pragma unroll
-            for (int fz = 0; fz < 4; ++fz) {
-                const f32x2 a0 = {acc[fz * 4 + 0][r], acc[fz * 4 + 0][r + 1]}, a1 = {acc[fz * 4 + 1][r], acc[fz * 4 + 1][r + 1]};
-                const f32x2 a2 = {acc[fz * 4 + 2][r], acc[fz * 4 + 2][r + 1]}, a3 = {acc[fz * 4 + 3][r], acc[fz * 4 + 3][r + 1]};
-                P[fz][0] = pk_add(pk_add(a0, a1), a2);
-                P[fz][1] = pk_sub(pk_sub(a1, a2), a3);
+                for (int fz = 0; fz < 4; ++fz) {
+                    const f32x2 a0 = {acc[fz * 4 + 0][r], acc[fz * 4 + 0][r + 1]}, a1 = {acc[fz * 4 + 1][r], acc[fz * 4 + 1][r + 1]};
+                    const f32x2 a2 = {acc[fz * 4 + 2][r], acc[fz * 4 + 2][r + 1]}, a3 = {acc[fz * 4 + 3][r], acc[fz * 4 + 3][r + 1]};
+                    P[fz][0] = pk_add(pk_add(a0, a1), a2);
+                    P[fz][1] = pk_sub(pk_sub(a1, a2), a3);
+                }
+                const int co = (r & 3) + 8 * (r >> 2);  // + 4 * half: in wr
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy) {
+                    *(f32x2 *)(wr + (0 + yy) * EPI_STAGE_FLOATS + co) = pk_add(pk_add(P[0][yy], P[1][yy]), P[2][yy]);
+                    *(f32x2 *)(wr + (2 + yy) * EPI_STAGE_FLOATS + co) = pk_sub(pk_sub(P[1][yy], P[2][yy]), P[3][yy]);
+                }
             }
+            W2_T(t_e1);
+            W2_ACC(3, t_e0, t_e1);
+            const int srow = lane_e >> 3, spiece = lane_e & 7;
+            const float *rd = stage + srow * EPI_PITCH + spiece * 4;
+            const int zb = cur.oz0 + 2 * bz, yb = cur.oy0 + 2 * by;
+            const int co0 = (int)blockIdx.y * 32;
+            const size_t row_elems = (size_t)p.Wo * p.Cout;
+            float *obase = p.out + (((size_t)cur.n * p.Do + zb) * p.Ho + yb) * row_elems + (size_t)cur.ox0 * p.Cout + co0;  // wave-uniform
+            const unsigned lane_off = (unsigned)(srow * p.Cout + spiece * 4);
+            const unsigned t_stride = (unsigned)(8 * p.Cout);
+            const f32x4 bias = *(const f32x4 *)(p.bias + co0 + spiece * 4);
+            const f32x2 b01 = {bias[0], bias[1]}, b23 = {bias[2], bias[3]};
+            // (a scalar across the tile loop; the vector copy is made here)
+            const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.act == ACT_LRELU ? p.slope : 1.0f)));
+            f32x2 slope2 = {slope, slope};
+            asm volatile("" : "+v"(slope2));
+            bool xok[4];
 #pragma unroll
-            for (int yy = 0; yy < 2; ++yy) {
-                const f32x2 o0 = pk_add(pk_add(P[0][yy], P[1][yy]), P[2][yy]);
-                const f32x2 o1 = pk_sub(pk_sub(P[1][yy], P[2][yy]), P[3][yy]);
-                out[0 + yy][0][r] = o0[0]; out[0 + yy][0][r + 1] = o0[1];
-                out[2 + yy][0][r] = o1[0]; out[2 + yy][0][r + 1] = o1[1];
+            for (int t = 0; t < 4; ++t) xok[t] = cur.ox0 + 8 * t + srow < p.Wo;
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                f32x4 raw[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) raw[t] = *(const f32x4 *)(rd + mf * EPI_STAGE_FLOATS + 8 * t * EPI_PITCH);
+                if (zb + (mf >> 1) >= p.Do || yb + (mf & 1) >= p.Ho) continue;  // wave-uniform
+                float *rowp = obase + ((size_t)(mf >> 1) * p.Ho + (mf & 1)) * row_elems;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    f32x2 x0 = {raw[t][0], raw[t][1]}, x1 = {raw[t][2], raw[t][3]}, y0, y1;
+                    f32x4 val;
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(x0) : "v"(x0), "v"(b01));
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(x1) : "v"(x1), "v"(b23));
+                    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y0) : "v"(x0), "v"(slope2));
+                    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y1) : "v"(x1), "v"(slope2));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(val[0]) : "v"(x0[0]), "v"(y0[0]));  // bare max: fmaxf would add a
+                    asm("v_max_f32 %0, %1, %2" : "=v"(val[1]) : "v"(x0[1]), "v"(y0[1]));  // canonicalising max per value
+                    asm("v_max_f32 %0, %1, %2" : "=v"(val[2]) : "v"(x1[0]), "v"(y1[0]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(val[3]) : "v"(x1[1]), "v"(y1[1]));
+#ifdef MI355_W2_ABL_NOSTORE
+                    asm volatile("" :: "v"(val));
+#else
+                    if (xok[t]) *(f32x4 *)(rowp + lane_off + t * t_stride) = val;
+#endif
+                }
             }
+            W2_T(t_e3);
+            // the barrier keeps the next chunk's DMAs of a faster wave out of the staging area until every wave has read its
+            // image back.  Raw barrier + lgkmcnt only: a __syncthreads() would also drain the stores (vmcnt(0)).
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            W2_T(t_e4);
+            W2_ACC(8, t_e3, t_e4);
+        } else {
+            f32x16 out[4][1];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 P[4][2];
+#pragma unroll
+                for (int fz = 0; fz < 4; ++fz) {
+                    const f32x2 a0 = {acc[fz * 4 + 0][r], acc[fz * 4 + 0][r + 1]}, a1 = {acc[fz * 4 + 1][r], acc[fz * 4 + 1][r + 1]};
+                    const f32x2 a2 = {acc[fz * 4 + 2][r], acc[fz * 4 + 2][r + 1]}, a3 = {acc[fz * 4 + 3][r], acc[fz * 4 + 3][r + 1]};
+                    P[fz][0] = pk_add(pk_add(a0, a1), a2);
+                    P[fz][1] = pk_sub(pk_sub(a1, a2), a3);
+                }
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy) {
+                    const f32x2 o0 = pk_add(pk_add(P[0][yy], P[1][yy]), P[2][yy]);
+                    const f32x2 o1 = pk_sub(pk_sub(P[1][yy], P[2][yy]), P[3][yy]);
+                    out[0 + yy][0][r] = o0[0]; out[0 + yy][0][r + 1] = o0[1];
+                    out[2 + yy][0][r] = o1[0]; out[2 + yy][0][r + 1] = o1[1];
+                }
+            }
+            // the shared epilogue with a 2-row y tile places fragment mf of wave w at z = 2w + (mf>>1), y = mf&1: shift its
+            // origin to this wave's block (z = 2bz + (mf>>1), y = 2by + (mf&1))
+            ConvArgs q = p;
+            q.lx = 5; q.ly = 1;
+            conv_epilogue<4, 1>(out, q, cur.n, cur.oz0 + 2 * bz - 2 * wave, cur.oy0 + 2 * by, cur.ox0, (int)blockIdx.y * 32, red,
+                                /*sync_before_red=*/false);
         }
-        // shared epilogue with a 2-row y tile: it places fragment mf of wave w at z = 2w + (mf>>1), y = mf&1, so
-        // shift the origin to this wave's block (z = 2bz + (mf>>1), y = 2by + (mf&1))
-        ConvArgs q = p;
-        q.lx = 5; q.ly = 1;
-        conv_epilogue<4, 1>(out, q, cur.n, cur.oz0 + 2 * bz - 2 * wave, cur.oy0 + 2 * by, cur.ox0, (int)blockIdx.y * 32, red,
-                            /*sync_before_red=*/false);
         cur = nxt_tile;
+        if (ntile < hi) {  // the next tile's first weight fragments (same cout block, chunk 0); they land while the accumulators are reset
+            static_for<0, 8>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                auto &u0 = uq[0]; const unsigned wl = k < 4 ? wl0 : wl1; const float *wb = wblk;
+                W2_ULOAD(u0[k], wl, wb, (k & 3) * 1024);
+            });
+        }
+        W2_T(t_e2);
+        W2_ACC(4, t_e0, t_e2);  // transform + stores (slot 3 = the transform part, PLAIN kernel only)
+        W2_CNT(7);
     }
+    W2_T(t_kernel1);
+    W2_ACC(5, t_kernel0, t_kernel1);
 #undef W2_ULOAD
 #undef W2_UWAIT
 }
@@ -1440,12 +1649,14 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
             static bool attr_set = false;
             if (!attr_set) {
                 MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brick_bytes));
-                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES));
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES));
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES));
                 attr_set = true;
             }
             float *zeros = nullptr;  // the zero page out-of-volume DMA pieces read
             MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
-            *kernel_name = w.wino2 ? "conv3_f32_wino2_kernel" : "conv3_f32_wino_kernel";
+            const bool plain = !c.stats && !c.head_out;
+            *kernel_name = w.wino2 ? (plain ? "conv3_f32_wino2_kernel<true>" : "conv3_f32_wino2_kernel<false>") : "conv3_f32_wino_kernel";
             if (w.wino2) {
                 Wino2Args wa;
                 wa.c = b; wa.total_tiles = (int)tiles; wa.zeros = zeros;
@@ -1454,7 +1665,8 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
                 gx = gx < 8 ? 8 : (gx / 8) * 8;         // multiple of 8: blockIdx.x & 7 labels the XCD group
                 const int need = (int)((tiles + 7) / 8) * 8;
                 if (gx > need) gx = need;
-                hipLaunchKernelGGL(conv3_f32_wino2_kernel, dim3(gx, gy), dim3(256), W2_LDS_BYTES, s, wa);
+                if (plain) hipLaunchKernelGGL(conv3_f32_wino2_kernel<true>, dim3(gx, gy), dim3(256), W2_LDS_BYTES, s, wa);
+                else hipLaunchKernelGGL(conv3_f32_wino2_kernel<false>, dim3(gx, gy), dim3(256), W2_LDS_BYTES, s, wa);
             } else {
                 hipLaunchKernelGGL(conv3_f32_wino_kernel, grid, dim3(256), brick_bytes, s, b);
             }
