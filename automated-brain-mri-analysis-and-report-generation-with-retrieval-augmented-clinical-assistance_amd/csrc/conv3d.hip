@@ -838,6 +838,12 @@ struct Wino2Args {
     const float *zeros;  // >= 16 B of zeros in global memory: the source of every out-of-volume piece
 };
 
+// Ablation switches of the diagnostic harness (tools/wino2_probe.hip -DMI355_W2_ABL=<bits>; results are then wrong by
+// design): 1 no epilogue, 2 no accumulator reset, 4 no brick DMA, 8 no weight loads, 16 no input transform,
+// 32 no global stores, 64 no store phase (read-back, bias, activation, stores).
+#ifndef MI355_W2_ABL
+#define MI355_W2_ABL 0
+#endif
 #ifdef MI355_W2_STAMPS
 // Diagnostic build only (tools/wino2_probe.hip): per-workgroup cycle sums of the kernel's phases, wave 0, via s_memtime.
 // Slots: 0 = chunk prologue, 1 = step loop, 2 = chunk-end drain + barrier, 3 = output transform, 4 = shared epilogue,
@@ -860,8 +866,11 @@ constexpr size_t W2_LDS_BYTES = (size_t)(2 * W2_BUF_FLOATS + 4 * 32 * 2) * sizeo
 // code for statistics or the fused head in the instantiation - their register demand made the allocator spill loop
 // invariants at kernel entry, and the epilogue's reloads missed every cache level after a chunk of streaming DMA traffic
 // (9-11k cycles per tile, tools/wino2_probe.hip stamps, round 2).
-template <bool PLAIN>
+// EPI: 0 = plain (above), 1 = fused 1x1x1 segmentation head (the network's last conv: only the logits are written),
+//      2 = the shared epilogue (Instance/GroupNorm statistics).
+template <int EPI>
 __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
+    constexpr bool PLAIN = EPI == 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const ConvArgs &p = pa.c;
@@ -921,10 +930,20 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
         // wave-uniform part (SALU); the per-lane part fits 32 bits (host check)
         src += ((((size_t)tc.n * p.Di + (tc.oz0 - 1)) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1)) * (long)Csrc + coff;
+#ifdef MI355_W2_RECOMPUTE_PK
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        int bvv = rng * 64 + ln;
+        const int over = bvv >= BV ? 1 : 0;
+        bvv -= over * BV;
+        const int rrr = bvv / IX, bx = bvv - rrr * IX;
+        const int rz = rrr / IY, ry = rrr - rz * IY;
+#else
         unsigned pk = dma_pk[k];
         asm volatile("" : "+v"(pk));  // unpack HERE, every time: hoisted out of the tile loop the unpacked fields and the 64-bit
                                       // offsets built from them are ~40 registers that get spilled to scratch at kernel entry
         const int rz = pk & 15, ry = (pk >> 4) & 15, bx = (pk >> 8) & 255, over = pk >> 16;
+#endif
         const bool in_vol = ((unsigned)(tc.oz0 - 1 + rz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + ry) < (unsigned)p.Hi) &&
                             ((unsigned)(tc.ox0 - 1 + bx) < (unsigned)p.Wi);
         const int voff = ((rz * p.Hi + ry) * p.Wi + bx) * Csrc + over * 4;
@@ -1011,9 +1030,11 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
         W2_T(t_t0);
         f32x16 acc[16];
 #pragma unroll
-        for (int f = 0; f < 16; ++f)
+        for (int f = 0; f < 16; ++f) {
+            if constexpr ((MI355_W2_ABL & 2) != 0) { asm volatile("" : "=a"(acc[f])); continue; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+        }
         const int ntile = tile + nl;
         const TileCoord nxt_tile = ntile < hi ? decode(ntile) : cur;
 
@@ -1068,7 +1089,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                     // the transform of step st+1 in four bunches of eight packed adds: a gap that holds any VALU work costs
                     // the matrix pipe ~5 cycles plus ~4.4 per instruction (tools/coissue_probe.hip), so 32 adds dealt one
                     // per gap cost twice what they cost in four gaps
-                    if constexpr (st + 1 < STEPS && (i == 0 || i == 2)) {
+                    if constexpr ((MI355_W2_ABL & 16) != 0) {
+                    } else if constexpr (st + 1 < STEPS && (i == 0 || i == 2)) {
                         static_for<0, 8>([&](auto u) { t_op(d, T, 4 * i + decltype(u)::value); });
                     } else if constexpr (st + 1 < STEPS && (i == 16 || i == 18)) {
                         static_for<0, 8>([&](auto u) { v_op(T, V[pp ^ 1], 4 * (i - 16) + decltype(u)::value); });
@@ -1078,13 +1100,14 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                     if constexpr (i < 16 && (i & 1) == 0) {
                         constexpr int k = i >> 1;
                         auto &un = uq[pp ^ 1]; const unsigned wl = k < 4 ? wl0 : wl1; const float *wb = wn;
-                        if (st + 1 < STEPS || !last_ch) W2_ULOAD(un[k], wl, wb, (k & 3) * 1024);
+                        if constexpr ((MI355_W2_ABL & 8) == 0)
+                            if (st + 1 < STEPS || !last_ch) W2_ULOAD(un[k], wl, wb, (k & 3) * 1024);
                     }
                     if constexpr (st + 2 < STEPS && i >= 8 && i < 16) {  // two rows per group (one ds_read2_b64), right after
                         d[2 * (i - 8)] = row_read(bufc, st + 2, 2 * (i - 8));          // the T ops released d: the data is
                         d[2 * (i - 8) + 1] = row_read(bufc, st + 2, 2 * (i - 8) + 1);  // needed 16 MFMAs later
                     }
-                    if constexpr ((st & 1) == 0 && st < 10 && i == 20) dma_group(nxt, nch_eff, st >> 1, bufn);
+                    if constexpr ((MI355_W2_ABL & 4) == 0 && (st & 1) == 0 && st < 10 && i == 20) dma_group(nxt, nch_eff, st >> 1, bufn);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
@@ -1101,7 +1124,10 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
 
         // Y = A^T M A: along y within each z component, then along z; rows ordered mf = 2*zrow + yrow (packed over
         // accumulator register pairs: the epilogue is pure VALU time on a SIMD that has nothing else to run)
-        if constexpr (PLAIN) {
+        if constexpr ((MI355_W2_ABL & 1) != 0) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f) asm volatile("" :: "a"(acc[f]));
+        } else if constexpr (PLAIN) {
             // Whole-line stores (see conv_epilogue_lines) through the brick buffer that has just been consumed - the other
             // one already holds the next tile's first chunk.  The output transform streams straight into the wave's LDS
             // image [fragment mf][voxel][cout] (8-B writes of two adjacent couts), so the 64 output values never exist
@@ -1116,6 +1142,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
             float *stage = lds + (buf ^ 1) * W2_BUF_FLOATS + wave * (4 * EPI_STAGE_FLOATS);
             float *wr = stage + (lane_e & 31) * EPI_PITCH + 4 * (lane_e >> 5);
+            const f32x4 bias = *(const f32x4 *)(p.bias + (int)blockIdx.y * 32 + (lane_e & 7) * 4);  // (lands during the transform)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 f32x2 P[4][2];
@@ -1132,6 +1159,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                     *(f32x2 *)(wr + (0 + yy) * EPI_STAGE_FLOATS + co) = pk_add(pk_add(P[0][yy], P[1][yy]), P[2][yy]);
                     *(f32x2 *)(wr + (2 + yy) * EPI_STAGE_FLOATS + co) = pk_sub(pk_sub(P[1][yy], P[2][yy]), P[3][yy]);
                 }
+                // one register pair of the 16 accumulators at a time: left alone the scheduler reads all 256 accumulator
+                // registers first, and that peak is what spills the tile loop's invariants to scratch
+                __builtin_amdgcn_sched_barrier(0);
             }
             W2_T(t_e1);
             W2_ACC(3, t_e0, t_e1);
@@ -1143,7 +1173,6 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
             float *obase = p.out + (((size_t)cur.n * p.Do + zb) * p.Ho + yb) * row_elems + (size_t)cur.ox0 * p.Cout + co0;  // wave-uniform
             const unsigned lane_off = (unsigned)(srow * p.Cout + spiece * 4);
             const unsigned t_stride = (unsigned)(8 * p.Cout);
-            const f32x4 bias = *(const f32x4 *)(p.bias + co0 + spiece * 4);
             const f32x2 b01 = {bias[0], bias[1]}, b23 = {bias[2], bias[3]};
             // (a scalar across the tile loop; the vector copy is made here)
             const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.act == ACT_LRELU ? p.slope : 1.0f)));
@@ -1154,6 +1183,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
             for (int t = 0; t < 4; ++t) xok[t] = cur.ox0 + 8 * t + srow < p.Wo;
 #pragma unroll
             for (int mf = 0; mf < 4; ++mf) {
+                if constexpr ((MI355_W2_ABL & 64) != 0) continue;
                 f32x4 raw[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) raw[t] = *(const f32x4 *)(rd + mf * EPI_STAGE_FLOATS + 8 * t * EPI_PITCH);
@@ -1171,11 +1201,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                     asm("v_max_f32 %0, %1, %2" : "=v"(val[1]) : "v"(x0[1]), "v"(y0[1]));  // canonicalising max per value
                     asm("v_max_f32 %0, %1, %2" : "=v"(val[2]) : "v"(x1[0]), "v"(y1[0]));
                     asm("v_max_f32 %0, %1, %2" : "=v"(val[3]) : "v"(x1[1]), "v"(y1[1]));
-#ifdef MI355_W2_ABL_NOSTORE
-                    asm volatile("" :: "v"(val));
-#else
-                    if (xok[t]) *(f32x4 *)(rowp + lane_off + t * t_stride) = val;
-#endif
+                    if constexpr ((MI355_W2_ABL & 32) != 0) asm volatile("" :: "v"(val));
+                    else if (xok[t]) *(f32x4 *)(rowp + lane_off + t * t_stride) = val;
                 }
             }
             W2_T(t_e3);
@@ -1185,6 +1212,75 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
             __builtin_amdgcn_s_barrier();
             W2_T(t_e4);
             W2_ACC(8, t_e3, t_e4);
+        } else if constexpr (EPI == 1) {
+            // Fused segmentation head: logit[c] = sum_cout w[c][cout] * act(y[cout] + b[cout]) + hb[c].  A lane holds 16 couts of
+            // its voxel (the other 16 sit in lane ^ 32), so the head is a dot product over registers plus one cross-half add,
+            // done inside the output transform one cout pair at a time: the 32-channel feature map exists neither in memory
+            // nor as 64 registers.  All weights this lane needs (4 bias quads, ncls x 4 head quads) are fetched once per tile,
+            // up front - loading them where they were used cost a memory round trip each (26k cycles per tile).
+            int lane_e;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+            const int co_l = 4 * (lane_e >> 5);  // this lane's couts: 8 g + co_l + k
+            constexpr int KMAX = 4;
+            f32x4 bq[4], hq[KMAX][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[g] = *(const f32x4 *)(p.bias + (int)blockIdx.y * 32 + 8 * g + co_l);
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    hq[c][g] = c < p.head_ncls ? *(const f32x4 *)(p.head_w + c * p.Cout + (int)blockIdx.y * 32 + 8 * g + co_l) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.act == ACT_LRELU ? p.slope : 1.0f)));
+            const f32x2 slope2 = {slope, slope};
+            f32x2 part[4][KMAX];
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) part[mf][c] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 P[4][2];
+#pragma unroll
+                for (int fz = 0; fz < 4; ++fz) {
+                    const f32x2 a0 = {acc[fz * 4 + 0][r], acc[fz * 4 + 0][r + 1]}, a1 = {acc[fz * 4 + 1][r], acc[fz * 4 + 1][r + 1]};
+                    const f32x2 a2 = {acc[fz * 4 + 2][r], acc[fz * 4 + 2][r + 1]}, a3 = {acc[fz * 4 + 3][r], acc[fz * 4 + 3][r + 1]};
+                    P[fz][0] = pk_add(pk_add(a0, a1), a2);
+                    P[fz][1] = pk_sub(pk_sub(a1, a2), a3);
+                }
+                const f32x2 b2 = {bq[r >> 2][r & 3], bq[r >> 2][(r & 3) + 1]};
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) {  // mf = 2 * zrow + yrow
+                    const int yy = mf & 1;
+                    f32x2 x = (mf >> 1) == 0 ? pk_add(pk_add(P[0][yy], P[1][yy]), P[2][yy]) : pk_sub(pk_sub(P[1][yy], P[2][yy]), P[3][yy]);
+                    f32x2 y;
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b2));
+                    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(x[0]) : "v"(x[0]), "v"(y[0]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(x[1]) : "v"(x[1]), "v"(y[1]));
+#pragma unroll
+                    for (int c = 0; c < KMAX; ++c) {
+                        const f32x2 w2 = {hq[c][r >> 2][r & 3], hq[c][r >> 2][(r & 3) + 1]};
+                        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(part[mf][c]) : "v"(x), "v"(w2));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int zb = cur.oz0 + 2 * bz, yb = cur.oy0 + 2 * by;
+            const int ox = cur.ox0 + (lane_e & 31);
+            const int64_t Vo = (int64_t)p.Do * p.Ho * p.Wo;
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const int oz = zb + (mf >> 1), oy = yb + (mf & 1);
+                const bool ok = oz < p.Do && oy < p.Ho && ox < p.Wo && lane_e < 32;
+                const int64_t vi = ((int64_t)oz * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) {
+                    if (c >= p.head_ncls) continue;  // uniform
+                    float v = part[mf][c][0] + part[mf][c][1];
+                    v += __shfl_xor(v, 32);
+                    if (ok) p.head_out[((int64_t)cur.n * p.head_ncls + c) * Vo + vi] = v + p.head_b[c];
+                }
+            }
         } else {
             f32x16 out[4][1];
 #pragma unroll
@@ -1649,14 +1745,16 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
             static bool attr_set = false;
             if (!attr_set) {
                 MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brick_bytes));
-                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES));
-                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES));
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES));
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES));
+                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES));
                 attr_set = true;
             }
             float *zeros = nullptr;  // the zero page out-of-volume DMA pieces read
             MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
-            const bool plain = !c.stats && !c.head_out;
-            *kernel_name = w.wino2 ? (plain ? "conv3_f32_wino2_kernel<true>" : "conv3_f32_wino2_kernel<false>") : "conv3_f32_wino_kernel";
+            const int epi = c.head_out ? 1 : (c.stats ? 2 : 0);
+            static const char *const w2_names[3] = {"conv3_f32_wino2_kernel<0>", "conv3_f32_wino2_kernel<1>", "conv3_f32_wino2_kernel<2>"};
+            *kernel_name = w.wino2 ? w2_names[epi] : "conv3_f32_wino_kernel";
             if (w.wino2) {
                 Wino2Args wa;
                 wa.c = b; wa.total_tiles = (int)tiles; wa.zeros = zeros;
@@ -1665,8 +1763,9 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
                 gx = gx < 8 ? 8 : (gx / 8) * 8;         // multiple of 8: blockIdx.x & 7 labels the XCD group
                 const int need = (int)((tiles + 7) / 8) * 8;
                 if (gx > need) gx = need;
-                if (plain) hipLaunchKernelGGL(conv3_f32_wino2_kernel<true>, dim3(gx, gy), dim3(256), W2_LDS_BYTES, s, wa);
-                else hipLaunchKernelGGL(conv3_f32_wino2_kernel<false>, dim3(gx, gy), dim3(256), W2_LDS_BYTES, s, wa);
+                if (epi == 0) hipLaunchKernelGGL(conv3_f32_wino2_kernel<0>, dim3(gx, gy), dim3(256), W2_LDS_BYTES, s, wa);
+                else if (epi == 1) hipLaunchKernelGGL(conv3_f32_wino2_kernel<1>, dim3(gx, gy), dim3(256), W2_LDS_BYTES, s, wa);
+                else hipLaunchKernelGGL(conv3_f32_wino2_kernel<2>, dim3(gx, gy), dim3(256), W2_LDS_BYTES, s, wa);
             } else {
                 hipLaunchKernelGGL(conv3_f32_wino_kernel, grid, dim3(256), brick_bytes, s, b);
             }

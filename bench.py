@@ -42,7 +42,8 @@ PATCH = (128, 128, 128)
 # Winograd kernels execute fewer multiplies than the algorithmic (direct-convolution) count that `achieved` uses:
 # F(2,3) along y issues 2/3 of the direct MFMAs, F(2x2,3x3) over (z,y) 4/9; frac can therefore exceed 1 and
 # frac_executed = matrix-pipe utilisation is reported beside it.
-EXECUTED_RATIO = {"conv3_f32_wino_kernel": 2.0 / 3.0, "conv3_f32_wino2_kernel<true>": 4.0 / 9.0, "conv3_f32_wino2_kernel<false>": 4.0 / 9.0}
+EXECUTED_RATIO = {"conv3_f32_wino_kernel": 2.0 / 3.0, "conv3_f32_wino2_kernel<0>": 4.0 / 9.0, "conv3_f32_wino2_kernel<1>": 4.0 / 9.0,
+                  "conv3_f32_wino2_kernel<2>": 4.0 / 9.0}
 
 WORKLOADS = {
     2: dict(models=[("A", 7)], tta=False, dtype="f32",

@@ -76,7 +76,7 @@ def test_forward_128_model_a(amd, gpu):
     # tolerance above is therefore the Winograd path's tolerance, not only the direct kernels'
     import os
     if os.environ.get("MI355_WINOGRAD", "2") not in ("0", "1") and os.environ.get("MI355_CONV_IMPL") is None:
-        assert "conv3_f32_wino2_kernel<true>" in kernels, sorted(kernels)
+        assert "conv3_f32_wino2_kernel<0>" in kernels, sorted(kernels)
 
 
 def _small_net(amd, norm="batch", seed=21):

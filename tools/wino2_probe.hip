@@ -17,7 +17,7 @@ int device_scratch(int slot, size_t bytes, void **out, bool zeroed) {
 }  // namespace mi355
 using namespace mi355;
 
-static int run(int N, int D, int cin, int cout, int reps) {
+static int run(int N, int D, int cin, int cout, int reps, bool head = false) {
     const size_t vin = (size_t)N * D * D * D;
     std::vector<float> x(vin * cin), w((size_t)cout * cin * 27), b(cout);
     uint32_t sd = 12345u;
@@ -32,6 +32,13 @@ static int run(int N, int D, int cin, int cout, int reps) {
     if (conv_weights_upload(w.data(), b.data(), cin, cin, cout, 1, false, &cw) != MI355_OK) return 1;
     ConvCall c;
     c.in0 = xd; c.C0 = cin; c.N = N; c.Di = D; c.Hi = D; c.Wi = D; c.out = yd; c.act = ACT_LRELU; c.slope = 0.01f;
+    float *hw = nullptr, *hb = nullptr, *hout = nullptr;
+    if (head) {  // the network's last decoder conv: fused 1x1x1 head, only the 3 logits are written
+        std::vector<float> w3(3 * cout, 0.01f), b3(3, 0.1f);
+        hipMalloc(&hw, w3.size() * 4); hipMalloc(&hb, 16); hipMalloc(&hout, vin * 3 * 4);
+        hipMemcpy(hw, w3.data(), w3.size() * 4, hipMemcpyHostToDevice); hipMemcpy(hb, b3.data(), 12, hipMemcpyHostToDevice);
+        c.head_w = hw; c.head_b = hb; c.head_out = hout; c.head_ncls = 3; c.out = nullptr;
+    }
     const char *name = nullptr;
     if (conv3d_mfma_f32(cw, c, 0, &name) != MI355_OK) return 1;
     hipDeviceSynchronize();
@@ -69,6 +76,7 @@ static int run(int N, int D, int cin, int cout, int reps) {
 int main() {
     // the wino2 launches of bench config 2 (8 tiles of 128^3 batched): level 0 32->32 and 64->32, level 1 64->64, 128->64, level 2 128->128
     if (run(8, 128, 32, 32, 3)) return 1;
+    if (run(8, 128, 32, 32, 3, true)) return 1;
     if (run(8, 128, 64, 32, 3)) return 1;
     if (run(8, 64, 64, 64, 5)) return 1;
     if (run(8, 64, 128, 64, 5)) return 1;
