@@ -75,6 +75,12 @@ static int run(int N, int D, int cin, int cout, int reps, bool head = false) {
 
 int main() {
     // the wino2 launches of bench config 2 (8 tiles of 128^3 batched): level 0 32->32 and 64->32, level 1 64->64, 128->64, level 2 128->128
+    if (getenv("W2_PROBE_PMC")) {  // one launch per shape (reps = 1 -> 2 launches incl. warm-up): traffic calibration under rocprofv3 --pmc
+        if (run(8, 128, 16, 32, 1)) return 1;
+        if (run(8, 128, 32, 32, 1)) return 1;
+        if (run(8, 64, 64, 64, 1)) return 1;
+        return 0;
+    }
     if (run(8, 128, 32, 32, 3)) return 1;
     if (run(8, 128, 32, 32, 3, true)) return 1;
     if (run(8, 128, 64, 32, 3)) return 1;
