@@ -49,6 +49,11 @@ struct ConvArgsH {
     int ksplit;
     float *partial;
     long out_elems;
+    // normalisation of the PRODUCER fused into this conv's staging (pipelined kernel, INAFF): in0 holds the raw conv output
+    // of the previous block, x' = act(x * in_scale[n][c] + in_shift[n][c]) is what the reference feeds this conv
+    // (generic_UNet.py:62-72: lrelu(instnorm(conv(x)))); out-of-volume voxels stay exactly zero (padding follows the norm)
+    const float *in_scale, *in_shift;  // [N][C0] fp32
+    int in_act;
 };
 
 // Epilogue shared by both kernels (C/D map of the 32x32 MFMA: col = lane&31 = voxel,
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256) void splitk_finish_f16_kernel(const float *par
 }
 
 // ------------------------------------------------------------------ pipelined persistent kernel (stride 1)
-template <int MF, int NF, bool HEAD = false>
+template <int MF, int NF, bool HEAD = false, bool INAFF = false>
 __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     constexpr int SLOTS = MF == 4 ? 11 : 8;  // 16-B staging pieces per thread and chunk
@@ -454,6 +459,53 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         return __builtin_bit_cast(f32x4, v);
     };
     auto slot_valid = [&](int r) { return (st_pk[r] >> 30) == 0; };
+    // INAFF: whether slot r's piece of the brick being staged lies inside the volume (same test as stage_issue)
+    auto slot_inside = [&](const TileCoord &tc, int faces, bool ragged, int r) {
+        const int pk = st_pk[r];
+        bool inside = (pk & ((faces | 64) << 24)) == 0;
+        if (ragged) {
+            const int bv = (r * 256 + tid) >> 1;
+            const int rr = (int)fdiv((uint32_t)bv, p.div_IX);
+            const int bx = bv - rr * IX;
+            const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
+            const int by = rr - bz * IY;
+            inside = ((pk >> 30) == 0) && ((unsigned)(tc.oz0 - 1 + bz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + by) < (unsigned)p.Hi) &&
+                     ((unsigned)(tc.ox0 - 1 + bx) < (unsigned)p.Wi);
+        }
+        return inside;
+    };
+    // INAFF: the producer's normalisation + activation on one staged piece (8 channels of one voxel): fp32 arithmetic on
+    // fp16 operands (v_fma_mix), one rounding to fp16.  Scale and shift are held as fp16 (8 registers instead of 16: the
+    // kernel runs at the 256-register limit of two waves per SIMD); that rounds them to 2^-11 relative, the precision of
+    // the activation itself.
+    auto in_affine = [&](f32x4 raw, f16x8 sc, f16x8 sh, float slope_in, bool inside) {
+        const f16x8 x = __builtin_bit_cast(f16x8, raw);
+        f16x8 y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (half_t)((float)x[j] * (float)sc[j] + (float)sh[j]);  // v_fma_mixlo/hi_f16: fp32 fma, one rounding
+        // LeakyReLU on the packed halfs: max(y, slope * y), 8 VALU instead of 20 in fp32 (a negative value is rounded twice)
+        const half_t sl = (half_t)slope_in;
+        const f16x8 sl8 = {sl, sl, sl, sl, sl, sl, sl, sl};
+        y = __builtin_elementwise_max(y, y * sl8);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        return inside ? __builtin_bit_cast(f32x4, y) : z;
+    };
+    const float slope_in = p.in_act == ACT_LRELU ? p.slope : 1.0f;
+    // per-(sample, channel) scale / shift of the 8 channels this thread stages in chunk `ch` of sample n (in0 only: the
+    // second half of a virtual concat is a skip tensor that was normalised when it was written)
+    auto load_aff = [&](int n, int ch, f16x8 &sc, f16x8 &sh) {
+        const int c0 = ch * 16 + (tid & 1) * 8;
+        const bool from_in0 = c0 < p.C0;
+        const float *ps = p.in_scale + (size_t)n * p.C0 + (from_in0 ? c0 : 0), *ph = p.in_shift + (size_t)n * p.C0 + (from_in0 ? c0 : 0);
+        const f32x4 s0 = *(const f32x4 *)ps, s1 = *(const f32x4 *)(ps + 4), h0 = *(const f32x4 *)ph, h1 = *(const f32x4 *)(ph + 4);
+        // (chunks of the second input get the identity: scale 1, shift 0, slope 1 - no branch in the tap loop)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[j] = from_in0 ? (half_t)s0[j] : (half_t)1.f; sc[4 + j] = from_in0 ? (half_t)s1[j] : (half_t)1.f;
+            sh[j] = from_in0 ? (half_t)h0[j] : (half_t)0.f; sh[4 + j] = from_in0 ? (half_t)h1[j] : (half_t)0.f;
+        }
+        return from_in0 ? slope_in : 1.0f;
+    };
 
     f32x16 acc[MF][NF];
     acc_init_bias<MF, NF>(acc, p.bias, (int)blockIdx.y * NF * 32, half);
@@ -471,10 +523,16 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
     const int co_blk = (int)blockIdx.y * NF * 32;
 
     TileCoord cur = decode(tile);
+    {
+        f16x8 sc0, sh0;
+        float sl0 = 1.f;
+        if constexpr (INAFF) sl0 = load_aff(cur.n, 0, sc0, sh0);
 #pragma unroll
-    for (int r = 0; r < SLOTS; ++r) {
-        const f32x4 v = stage_issue(cur, tile_faces(cur), tile_ragged(cur), 0, r);
-        if (slot_valid(r)) *(f32x4 *)(lds_raw + dst0 + r * 2048) = v;
+        for (int r = 0; r < SLOTS; ++r) {
+            f32x4 v = stage_issue(cur, tile_faces(cur), tile_ragged(cur), 0, r);
+            if constexpr (INAFF) v = in_affine(v, sc0, sh0, sl0, slot_inside(cur, tile_faces(cur), tile_ragged(cur), r));
+            if (slot_valid(r)) *(f32x4 *)(lds_raw + dst0 + r * 2048) = v;
+        }
     }
     f16x8 bq[BD][NF];
 #pragma unroll
@@ -510,27 +568,32 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) a[0][mf] = *(lds_cf16x8 *)(ab[mf]);
         f32x4 st_v[SLOTS];
+        f16x8 sc_n, sh_n;  // INAFF: scale / shift of the chunk being staged (loaded with the first fetch, used FLIGHT taps later)
+        float sl_n = 1.f;
+        if constexpr (INAFF) sl_n = load_aff(nxt.n, nch_eff, sc_n, sh_n);
 
-#pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
+        // (compile-time tap and slot indices: a "#pragma unroll" the optimiser declines turns a[tap & 1], bq[tap % BD] and
+        //  st_v[tap] into select chains over whole register arrays)
+        static_for<0, 27>([&](auto tap_c) {
+            constexpr int tap = decltype(tap_c)::value;
             // ---- all memory instructions of the step first (next step's voxel fragments, the weight fragment
             // BD steps ahead, one staging fetch), pinned ahead of the MFMAs so that every fragment has a full
             // step of MFMA time to arrive (the compiler otherwise sinks the LDS reads to just before their use)
             f16x8 bnew[NF];
-            if (tap + 1 < 27) {
-                const int nt = tap + 1;
-                const int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
+            if constexpr (tap + 1 < 27) {
+                constexpr int nt = tap + 1;
+                constexpr int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
                 const int off = ((dz * IY + dy) * IX + dx) * 16;
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf) a[(tap + 1) & 1][mf] = *(lds_cf16x8 *)(ab[mf] + off);
             }
             {
-                const int k = tap + BD;
+                constexpr int k = tap + BD;
                 const unsigned wsrc = (k < 27) ? wch + k * (NF * 512) : wnx + (k - 27) * (NF * 512);
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) bnew[nf] = wload(wsrc + nf * 512);
             }
-            if (tap < SLOTS) st_v[tap] = stage_issue(nxt, nfaces, nragged, nch_eff, tap);
+            if constexpr (tap < SLOTS) st_v[tap] = stage_issue(nxt, nfaces, nragged, nch_eff, tap);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
@@ -539,13 +602,18 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
                     acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[tap % BD][nf], a[tap & 1][mf], acc[mf][nf], 0, 0, 0);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) bq[tap % BD][nf] = bnew[nf];
-#pragma unroll
-            for (int r = 0; r < SLOTS; ++r) {
-                const int wr = r + FLIGHT < 26 ? r + FLIGHT : 26;
-                if (wr == tap && have_next && slot_valid(r)) *(f32x4 *)(bufn + dst0 + r * 2048) = st_v[r];
-            }
+            static_for<0, SLOTS>([&](auto r_c) {
+                constexpr int r = decltype(r_c)::value;
+                constexpr int wr = r + FLIGHT < 26 ? r + FLIGHT : 26;
+                if constexpr (wr == tap) {
+                    if (have_next && slot_valid(r)) {
+                        if constexpr (INAFF) st_v[r] = in_affine(st_v[r], sc_n, sh_n, sl_n, slot_inside(nxt, nfaces, nragged, r));
+                        *(f32x4 *)(bufn + dst0 + r * 2048) = st_v[r];
+                    }
+                }
+            });
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
         __syncthreads();
 
         if (ch == p.nchunks - 1) {
@@ -798,6 +866,18 @@ static bool use_pipe_h() {
     return v == 1;
 }
 
+// Whether conv3d_mfma_f16 would run this call on the pipelined stride-1 kernel, the one that can apply the producer's
+// normalisation while staging (register staging; the LDS-DMA and split-K kernels cannot).  Mirrors the dispatch below.
+bool conv3d_f16_fuses_input_norm(const ConvWeightsH &w, const ConvCallH &c) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("MI355_FUSE_NORM"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || w.stride != 1 || !use_pipe_h() || c.head_out || c.C0 % 16 != 0) return false;
+    static int splitk = -1;
+    if (splitk < 0) { const char *e = getenv("MI355_SPLITK"); splitk = (e && e[0] == '0') ? 0 : 1; }
+    if (splitk && !c.stats && w.cin_pad / 16 >= 8) return false;  // might take the split-K path: keep it simple
+    return true;
+}
+
 int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, const char **kernel_name) {
     MI355_REQUIRE(c.C0 + c.C1 == w.cin_pad, "conv input channels %d+%d != %d", c.C0, c.C1, w.cin_pad);
     MI355_REQUIRE(c.C0 % 16 == 0 && c.C1 % 16 == 0, "fp16 concat split %d/%d not a multiple of 16", c.C0, c.C1);
@@ -817,6 +897,8 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
     a.total_tiles = 0;
     a.zeros = nullptr;
     a.ksplit = 1; a.partial = nullptr; a.out_elems = 0;
+    a.in_scale = c.in_scale; a.in_shift = c.in_shift; a.in_act = c.in_act;
+    MI355_REQUIRE(!c.in_scale || (c.in_shift && conv3d_f16_fuses_input_norm(w, c)), "input normalisation can only be fused into the pipelined stride-1 kernel");
     const int gy = w.cout / (32 * w.nf);
     static size_t attr[8] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
     {
@@ -882,6 +964,13 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
             static size_t attr_head[2] = {48 * 1024, 48 * 1024};  // one slot per kernel: the attribute is per function
             if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, true>, a, grid, lds_bytes, s, &attr_head[0]);
             return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, true>, a, grid, lds_bytes, s, &attr_head[1]);
+        }
+        if (c.in_scale) {  // the producer's normalisation + activation applied while the brick is staged
+            static size_t attr_aff[3] = {48 * 1024, 48 * 1024, 48 * 1024};
+            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false, true>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false, true>" : "conv3_f16_mfma_pipe_kernel<2, 2, false, true>");
+            if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, false, true>, a, grid, lds_bytes, s, &attr_aff[0]);
+            if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, false, true>, a, grid, lds_bytes, s, &attr_aff[1]);
+            return launch_h(conv3_f16_mfma_pipe_kernel<2, 2, false, true>, a, grid, lds_bytes, s, &attr_aff[2]);
         }
         if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1>, a, grid, lds_bytes, s, &attr[0]);
         if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1>, a, grid, lds_bytes, s, &attr[1]);

@@ -77,7 +77,12 @@ struct ConvCallH {
     const float *head_w = nullptr, *head_b = nullptr;  // fused segmentation head, see ConvCall
     float *head_out = nullptr;
     int head_ncls = 0;
+    // in0 is the RAW conv output of the previous block: apply x * in_scale[n][c] + in_shift[n][c] (+ LeakyReLU when in_act)
+    // while staging it (only where conv3d_f16_fuses_input_norm says so)
+    const float *in_scale = nullptr, *in_shift = nullptr;
+    int in_act = ACT_NONE;
 };
+bool conv3d_f16_fuses_input_norm(const ConvWeightsH &w, const ConvCallH &c);
 int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, const char **kernel_name = nullptr);
 
 // ---------------------------------------------------------------- transposed conv k=2 s=2

@@ -201,6 +201,7 @@ struct Plan {
     std::vector<int> maxc;             // widest tensor at each level
     std::vector<size_t> off[4];        // byte offsets of buffers A, B, U, T per level
     size_t stats_off = 0, scale_off = 0, shift_off = 0, x0_off = 0, total = 0;
+    size_t scale2_off = 0, shift2_off = 0;  // second scale / shift pair: a block whose normalisation is applied by its consumer
     size_t stats_bytes = 0;
 };
 
@@ -231,6 +232,8 @@ static int make_plan(const mi355_unet &net, int N, int D, int H, int W, Plan *pl
     pl->stats_off = take(pl->stats_bytes);
     pl->scale_off = take((size_t)N * net.max_channels * sizeof(float));
     pl->shift_off = take((size_t)N * net.max_channels * sizeof(float));
+    pl->scale2_off = take((size_t)N * net.max_channels * sizeof(float));
+    pl->shift2_off = take((size_t)N * net.max_channels * sizeof(float));
     pl->total = o;
     return MI355_OK;
 }
@@ -269,12 +272,14 @@ static std::string conv_kernel_name(const ConvWeights &w) {
 }
 
 // One ConvDropoutNormNonlin / ConvDropoutNonlinNorm block.
+// `defer_norm`: the block's normalisation (+ activation) is NOT applied to `out`; its per-(sample, channel) scale / shift go
+// to the plan's second pair and the NEXT block applies them while staging its input (`in_norm` of that call).
 static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const void *in0, int C0,
                      const void *in1, int C1, int N, int Di, int Hi, int Wi, void *out, hipStream_t s,
-                     float *head_logits_out = nullptr) {
+                     float *head_logits_out = nullptr, bool defer_norm = false, bool in_norm = false) {
     const bool f16 = net->dtype == MI355_F16;
     double *stats = (double *)(net->arena + pl.stats_off);
-    float *scale = (float *)(net->arena + pl.scale_off), *shift = (float *)(net->arena + pl.shift_off);
+    float *scale = (float *)(net->arena + (defer_norm ? pl.scale2_off : pl.scale_off)), *shift = (float *)(net->arena + (defer_norm ? pl.shift2_off : pl.shift_off));
     int act = ACT_LRELU;
     double *stats_arg = nullptr;
     if (L.runtime_norm) {
@@ -298,6 +303,10 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
             c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi; c.out = (_Float16 *)out; c.slope = net->slope;
             c.act = act; c.stats = stats_arg;
             if (head_logits_out) { c.head_w = net->head.w_dev; c.head_b = net->head.b_dev; c.head_ncls = net->head.ncls; c.head_out = head_logits_out; }
+            if (in_norm) {  // in0 is the previous block's raw conv output: normalise (+ LeakyReLU) while staging
+                c.in_scale = (const float *)(net->arena + pl.scale2_off); c.in_shift = (const float *)(net->arena + pl.shift2_off);
+                c.in_act = net->nonlin_first ? ACT_NONE : ACT_LRELU;
+            }
             const char *kname = nullptr;
             ProfScope ps(net, s, "conv3_f16", flops, bytes);
             MI355_TRY(conv3d_mfma_f16(L.wh, c, s, &kname));
@@ -319,6 +328,7 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
     if (L.runtime_norm) {
         MI355_TRY(norm_finalize(stats, N, L.cout, Vo, net->norm, net->num_groups, net->eps, L.gamma_dev, L.beta_dev,
                                 scale, shift, s));
+        if (defer_norm) return MI355_OK;  // the consumer applies scale / shift (and the activation) in its staging
         ProfScope ps(net, s, f16 ? "norm_apply_kernel<f16>" : "norm_apply_kernel<f32>", 2.0 * N * Vo * L.cout, 2.0 * es * N * Vo * L.cout);
         MI355_TRY(norm_apply(out, net->dtype, N, Vo, L.cout, scale, shift, net->nonlin_first ? ACT_NONE : ACT_LRELU, net->slope, s));
     } else if (L.post_affine) {
@@ -328,6 +338,18 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
                                  ACT_NONE, net->slope, s));
     }
     return MI355_OK;
+}
+
+// Can block `L` (run-time Instance/GroupNorm) leave its normalisation to the next block `Ln` of the same stage?  fp16 only:
+// the consumer must be the register-staged pipelined stride-1 kernel (conv3d_f16_fuses_input_norm); the f32 path stages its
+// bricks by LDS-DMA and keeps the separate pass.  generic_UNet.py:62-72 is one expression, lrelu(instnorm(conv(x))).
+static bool can_defer_norm(const mi355_unet *net, const ConvLayer &L, const ConvLayer &Ln, int N, int Dl, int Hl, int Wl) {
+    if (net->dtype != MI355_F16 || !L.runtime_norm || L.is_stem == false && !L.wh.wp_dev) return false;
+    if (Ln.stride != 1 || Ln.is_stem || !Ln.wh.wp_dev || Ln.cin != L.cout) return false;
+    ConvCallH c;
+    c.C0 = L.cout; c.C1 = 0; c.N = N; c.Di = Dl; c.Hi = Hl; c.Wi = Wl;
+    c.stats = Ln.runtime_norm ? (double *)1 : nullptr;  // (only tested for null)
+    return conv3d_f16_fuses_input_norm(Ln.wh, c);
 }
 
 // x0: [N,D,H,W,cin_pad] already in the arena at pl.x0_off.  Returns the last decoder feature map.
@@ -346,12 +368,15 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
     // encoder + bottleneck
     for (int l = 0; l <= np; ++l) {
         int Di = D >> l, Hi = H >> l, Wi = W >> l;
+        bool pending = false;  // cur holds a raw conv output whose normalisation the next block applies
         for (size_t i = 0; i < net->enc[l].size(); ++i) {
             const ConvLayer &L = net->enc[l][i];
             int inD = Di, inH = Hi, inW = Wi;
             if (L.stride == 2) { inD = Di * 2; inH = Hi * 2; inW = Wi * 2; }
             void *out = buf((int)(i & 1), l);
-            MI355_TRY(run_block(net, pl, L, cur, curC, nullptr, 0, N, inD, inH, inW, out, s));
+            const bool defer = i + 1 < net->enc[l].size() && can_defer_norm(net, L, net->enc[l][i + 1], N, Di, Hi, Wi);
+            MI355_TRY(run_block(net, pl, L, cur, curC, nullptr, 0, N, inD, inH, inW, out, s, nullptr, defer, pending));
+            pending = defer;
             cur = out; curC = L.cout;
         }
         if (l < np) { skip[l] = cur; skipC[l] = curC; }
@@ -376,6 +401,7 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
         int C0 = tcout, C1 = skipC[l];
         // outputs alternate between T and whichever of A/B is not the skip
         void *freeAB = (skip[l] == buf(0, l)) ? buf(1, l) : buf(0, l);
+        bool pending_d = false;
         for (size_t i = 0; i < net->dec[u].size(); ++i) {
             const ConvLayer &L = net->dec[u][i];
             void *out = (i & 1) ? freeAB : buf(3, l);
@@ -396,7 +422,9 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
                 *feat = lg; *feat_c = net->head.ncls;
                 return MI355_OK;
             }
-            MI355_TRY(run_block(net, pl, L, in0, C0, in1, C1, N, Dl, Hl, Wl, out, s));
+            const bool defer = i + 1 < net->dec[u].size() && can_defer_norm(net, L, net->dec[u][i + 1], N, Dl, Hl, Wl);
+            MI355_TRY(run_block(net, pl, L, in0, C0, in1, C1, N, Dl, Hl, Wl, out, s, nullptr, defer, pending_d));
+            pending_d = defer;
             in0 = out; C0 = L.cout; in1 = nullptr; C1 = 0;
         }
         cur = in0; curC = C0;

@@ -181,6 +181,45 @@ def test_forward_f16_batch_ragged_and_simple_kernel(amd, gpu, monkeypatch):
         _check_logits_f16(got[n:n + 1], ref[n:n + 1])
 
 
+def test_f16_fused_input_norm_agrees_with_the_separate_pass(amd, gpu):
+    """The Instance/GroupNorm of a stage's first conv is applied by the second conv while it stages its input (no
+    norm_apply pass).  Same math as the separate pass except that scale and shift are rounded to fp16: the logits of the
+    two builds agree to a small fraction of the fp16 path's own error against the oracle.  The switch is read once per
+    process, so the un-fused build runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import brats_amd
+sd, meta = brats_amd.synthetic.make_model("B", seed=7)
+net = brats_amd.UNet(sd, norm="group", num_groups=16, dtype="f16")
+x = np.random.RandomState(1).standard_normal((1, 4, 64, 64, 64)).astype(np.float32)
+net.profile(True)
+y = net(torch.from_numpy(x).cuda()).cpu().numpy()
+names = sorted(e["name"] for e in net.read_profile())
+np.savez(sys.argv[1], y=y, names=np.array(names))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("1", "0"):
+            path = os.path.join(td, f"y{flag}.npz")
+            res = subprocess.run([sys.executable, "-c", code % root, path], env=dict(os.environ, MI355_FUSE_NORM=flag),
+                                 capture_output=True, text=True, timeout=600)
+            assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+            outs[flag] = np.load(path)
+    fused, plain = outs["1"], outs["0"]
+    assert any("false, true>" in n for n in fused["names"]), list(fused["names"])         # the INAFF kernels ran ...
+    assert not any("false, true>" in n for n in plain["names"])
+    spread = float(plain["y"].std())
+    err = float(np.abs(fused["y"] - plain["y"]).max())
+    print(f"PARITY fused-vs-separate norm (f16, B 64^3): {err / spread:.2e} x spread")
+    assert err <= 2e-2 * spread  # (measured 8.5e-3: what any 2^-11 perturbation of an early activation grows to; each build is within 2.3e-2 of the oracle)
+
+
 def test_sliding_window_f16_tta(amd, gpu):
     sd = _small_net(amd)
     net = amd.UNet(sd, norm="batch", dtype="f16")

@@ -41,6 +41,8 @@ CONV_CASES = [
     (2, 4, 4, 4, 320, 320, 1, 1),      # bottleneck-sized launch: split-K with a 64-voxel volume in 256-voxel tiles
     (1, 64, 64, 64, 32, 64, 1, 1),     # >= 512 workgroups: the Winograd kernel (F(2x2,3x3) by default), two cout blocks
     (3, 30, 37, 70, 48, 32, 1, 0),     # Winograd kernel: ragged in z, y (odd: half-used row pair) and x, 3 chunks, batch
+    (2, 16, 64, 128, 16, 32, 1, 1),    # Winograd kernel: ONE 16-channel chunk per tile, 4 x 16 x 4 tiles per sample -> blocked tile order 4 x 4 x 2
+    (1, 24, 64, 256, 32, 32, 1, 1),    # Winograd kernel: 8 x-tiles and 6 z-tiles (not a power of two -> linear tile order), whole-line stores
 ]
 
 
