@@ -836,12 +836,7 @@ struct Wino2Args {
     ConvArgs c;
     int total_tiles;
     const float *zeros;  // >= 16 B of zeros in global memory: the source of every out-of-volume piece
-    // Blocked tile order (conv3_f32_wino2_kernel): within a sample, tile ids run through blocks of 2^lbx x 2^lby x 2^lbz
-    // tiles (32 tiles when the grid allows), x fastest inside a block and over the blocks.  The 32 workgroups of an XCD
-    // work on 32 consecutive ids, so at any time they cover one compact 3-D block whose halos overlap inside that XCD's
-    // L2 (4x4x2 tiles: 1.43 input voxels fetched per output voxel instead of 1.62 for a 4x8x1 slab).
-    int lbx, lby, lbz;
-    FastDiv div_nbx, div_nby;  // blocks per row / per slab
+    TileOrder order;  // blocked tile order (common.h)
 };
 
 // Ablation switches of the diagnostic harness (tools/wino2_probe.hip -DMI355_W2_ABL=<bits>; results are then wrong by
@@ -905,15 +900,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
         TileCoord tc;
         tc.n = (int)fdiv((uint32_t)t, p.div_tiles_per_n);
         const int tt = t - tc.n * (int)p.div_tiles_per_n.d;
-        const int lb = pa.lbx + pa.lby + pa.lbz;
-        const int w = tt & ((1 << lb) - 1), blk = tt >> lb;               // tile within its block, block within the sample
-        const int bzy = (int)fdiv((uint32_t)blk, pa.div_nbx);
-        const int bxi = blk - bzy * (int)pa.div_nbx.d;
-        const int bzi = (int)fdiv((uint32_t)bzy, pa.div_nby);
-        const int byi = bzy - bzi * (int)pa.div_nby.d;
-        const int tile_x = (bxi << pa.lbx) + (w & ((1 << pa.lbx) - 1));
-        const int tile_y = (byi << pa.lby) + ((w >> pa.lbx) & ((1 << pa.lby) - 1));
-        const int tile_z = (bzi << pa.lbz) + (w >> (pa.lbx + pa.lby));
+        int tile_x, tile_y, tile_z;
+        tile_from_id(tt, pa.order, tile_x, tile_y, tile_z);
         tc.oz0 = tile_z << 2; tc.oy0 = tile_y << 2; tc.ox0 = tile_x << 5;
         return tc;
     };
@@ -1391,10 +1379,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
         TileCoord tc;
         tc.n = (int)fdiv((uint32_t)t, p.div_tiles_per_n);
         const int tt = t - tc.n * (int)p.div_tiles_per_n.d;
-        const int tzy = (int)fdiv((uint32_t)tt, p.div_tiles_x);
-        const int tile_x = tt - tzy * p.tiles_x;
-        const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
-        const int tile_y = tzy - tile_z * p.tiles_y;
+        int tile_x, tile_y, tile_z;
+        tile_from_id(tt, pa.order, tile_x, tile_y, tile_z);
         tc.oz0 = tile_z << 1; tc.oy0 = tile_y * GM::TY; tc.ox0 = tile_x << TXL;
         return tc;
     };
@@ -1772,23 +1758,7 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
             if (w.wino2) {
                 Wino2Args wa;
                 wa.c = b; wa.total_tiles = (int)tiles; wa.zeros = zeros;
-                {   // blocked tile order: 32-tile blocks as cubic as the (power-of-two) grid allows, else linear order
-                    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-                    int lbx = 0, lby = 0, lbz = 0;
-                    if (pow2(b.tiles_x) && pow2(b.tiles_y) && pow2(b.tiles_z) && (long)b.tiles_x * b.tiles_y * b.tiles_z >= 32) {
-                        while ((1 << lbx) < b.tiles_x && lbx < 2) ++lbx;  // x tiles are 32 voxels wide: at most 4 of them
-                        int rest = 5 - lbx;
-                        while (rest > 0) {  // deal the remaining factors of two to y and z alternately, y first
-                            if ((1 << lby) < b.tiles_y && (lby <= lbz || (1 << lbz) >= b.tiles_z)) { ++lby; --rest; }
-                            else if ((1 << lbz) < b.tiles_z) { ++lbz; --rest; }
-                            else break;
-                        }
-                        if (rest > 0) lbx = lby = lbz = 0;
-                    }
-                    wa.lbx = lbx; wa.lby = lby; wa.lbz = lbz;
-                    wa.div_nbx = make_fastdiv(b.tiles_x >> lbx);
-                    wa.div_nby = make_fastdiv(b.tiles_y >> lby);
-                }
+                wa.order = make_tile_order(b.tiles_x, b.tiles_y, b.tiles_z);
                 const int gy = w.cout / 32;
                 int gx = 256 / gy;                      // one persistent workgroup per CU
                 gx = gx < 8 ? 8 : (gx / 8) * 8;         // multiple of 8: blockIdx.x & 7 labels the XCD group
@@ -1924,6 +1894,7 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
             MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
             Wino2Args wa;
             wa.c = b; wa.total_tiles = (int)tiles; wa.zeros = zeros;
+            wa.order = make_tile_order(b.tiles_x, b.tiles_y, b.tiles_z);
             int gx = 256 / gy;
             gx = gx < 8 ? 8 : (gx / 8) * 8;
             const int need = (int)((tiles + 7) / 8) * 8;

@@ -43,6 +43,7 @@ struct ConvArgsH {
     const float *head_w, *head_b;  // fused 1x1x1 head (see ConvCall)
     float *head_out;
     int head_ncls;
+    TileOrder order;  // blocked tile order of the persistent stride-2 kernel (common.h)
     int plane_bytes;  // brickvox * 16
     const void *zeros;  // >= 32 B of zeros in global memory (stride-2 DMA kernel: source of out-of-volume pieces)
     // split-K (simple kernel, small launches): blockIdx.z = slice of the channel chunks; fp32 partial sums go to `partial`
@@ -74,7 +75,16 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[MF][NF], const float
         }
 }
 
-template <int MF, int NF, bool HEAD = false>
+// SC1: the output lines leave the XCD's L2 with the store (global_store ... sc1).  For the persistent LDS-DMA kernels: nothing
+// on this XCD reads the output again, and kept in L2 it evicts the brick lines that the next channel chunk of the same
+// voxels is about to fetch a second part of (conv3_f32_wino2_kernel: FETCH_SIZE -38 % with this flag alone).
+template <bool SC1>
+__device__ __forceinline__ void store_f16x4(half_t *ptr, f16x4 v) {
+    if constexpr (SC1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+    else *(f16x4 *)ptr = v;
+}
+
+template <int MF, int NF, bool HEAD = false, bool SC1 = false>
 __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const ConvArgsH &p, int n, int oz0, int oy0,
                                                   int ox0, int co_blk, float *red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -159,7 +169,7 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
                         val[k] = (half_t)m0;
                         val[k + 1] = (half_t)m1;
                     }
-                    if (ok) *(f16x4 *)(orow + nf * 32 + 8 * g) = val;
+                    if (ok) store_f16x4<SC1>(orow + nf * 32 + 8 * g, val);
                 }
         }
         return;
@@ -187,7 +197,7 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
                     val[k] = (half_t)x;
                     if (ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
                 }
-                if (ok) *(f16x4 *)(orow + nf * 32 + 8 * g) = val;
+                if (ok) store_f16x4<SC1>(orow + nf * 32 + 8 * g, val);
             }
         }
     }
@@ -664,10 +674,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(ConvArgsH p) {
         TileCoord tc;
         tc.n = (int)fdiv((uint32_t)t, p.div_tiles_per_n);
         const int tt = t - tc.n * (int)p.div_tiles_per_n.d;
-        const int tzy = (int)fdiv((uint32_t)tt, p.div_tiles_x);
-        const int tile_x = tt - tzy * p.tiles_x;
-        const int tile_z = (int)fdiv((uint32_t)tzy, p.div_tiles_y);
-        const int tile_y = tzy - tile_z * p.tiles_y;
+        int tile_x, tile_y, tile_z;
+        tile_from_id(tt, p.order, tile_x, tile_y, tile_z);
         tc.oz0 = tile_z << 1; tc.oy0 = tile_y * GM::TY; tc.ox0 = tile_x << TXL;
         return tc;
     };
@@ -773,7 +781,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(ConvArgsH p) {
         }
         ConvArgsH q = p;
         q.lx = TXL; q.ly = 6 - TXL; q.lz = 1;  // voxel v = wave * 32 + lane: x = v & (TX-1), y = (v >> TXL) & (TY-1), z = v >> 6
-        conv_epilogue_f16<1, 2>(acc, q, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red);
+        conv_epilogue_f16<1, 2>(acc, q, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red);  // (8-B sc1 stores cost 2.7x per byte: not here)
         if (p.stats) __syncthreads();  // the statistics scratch is reused by the next tile
         cur = nxt_tile;
     }
@@ -1004,6 +1012,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
             MI355_TRY(device_scratch(SCR_ZEROS, 256, &zeros, true));
             b.zeros = zeros;
             b.total_tiles = (int)tiles;
+            b.order = make_tile_order(b.tiles_x, b.tiles_y, b.tiles_z);
             int gx = 256 / gy2;
             gx = gx < 8 ? 8 : (gx / 8) * 8;
             const int need = (int)((tiles + 7) / 8) * 8;
