@@ -220,7 +220,7 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
         double tot = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
-        atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, tot);
+        atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, quantise_partial(tot, k, (long)p.Do * p.Ho * p.Wo));  // exact, hence order-independent (common.h)
     }
 }
 

@@ -118,7 +118,7 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) tot += (double)red[(w * 32 + c) * 2 + k];
-            atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, tot);
+            atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, quantise_partial(tot, k, (long)p.D * p.H * p.W));  // exact, hence order-independent (common.h)
         }
     }
 }

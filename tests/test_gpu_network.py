@@ -49,6 +49,20 @@ def test_forward_batch_and_ragged_patch(amd, gpu):
     _check_logits(got, ref)
 
 
+def test_instance_and_group_norm_forwards_are_bit_reproducible(amd, gpu):
+    """the Instance/GroupNorm sums are accumulated with atomics in arrival order; every partial is rounded to a
+    fixed quantum first, which makes the fp64 additions exact and the result independent of that order (common.h:
+    quantise_partial).  Five forwards of each model, fp32 and fp16, must agree bit for bit."""
+    x = torch.from_numpy(np.random.RandomState(9).standard_normal((2, 4, 64, 64, 64)).astype(np.float32)).to(gpu)
+    for name, dtype in (("A_in", "f32"), ("B", "f32"), ("A_in", "f16"), ("B", "f16")):
+        sd, meta = amd.synthetic.make_model(name, seed=7)
+        net = amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"], dtype=dtype)
+        first = net(x).clone()
+        for _ in range(4):
+            assert torch.equal(net(x), first), (name, dtype)
+        net.close()
+
+
 def test_forward_nonlin_first_variants(amd, gpu):
     """ConvDropoutNonlinNorm ordering (generic_UNet.py:75-80) with GroupNorm and BatchNorm."""
     for norm in ("group", "batch"):
