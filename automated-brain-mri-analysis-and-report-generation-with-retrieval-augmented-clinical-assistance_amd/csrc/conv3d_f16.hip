@@ -484,21 +484,16 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         }
         return inside;
     };
-    // INAFF: the producer's normalisation + activation on one staged piece (8 channels of one voxel): fp32 arithmetic on
-    // fp16 operands (v_fma_mix), one rounding to fp16.  Scale and shift are held as fp16 (8 registers instead of 16: the
-    // kernel runs at the 256-register limit of two waves per SIMD); that rounds them to 2^-11 relative, the precision of
-    // the activation itself.
-    auto in_affine = [&](f32x4 raw, f16x8 sc, f16x8 sh, float slope_in, bool inside) {
-        const f16x8 x = __builtin_bit_cast(f16x8, raw);
-        f16x8 y;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = (half_t)((float)x[j] * (float)sc[j] + (float)sh[j]);  // v_fma_mixlo/hi_f16: fp32 fma, one rounding
-        // LeakyReLU on the packed halfs: max(y, slope * y), 8 VALU instead of 20 in fp32 (a negative value is rounded twice)
-        const half_t sl = (half_t)slope_in;
-        const f16x8 sl8 = {sl, sl, sl, sl, sl, sl, sl, sl};
+    // INAFF: the producer's normalisation + activation on one staged piece (8 channels of one voxel), all in packed fp16:
+    // v_pk_fma_f16 (x * scale + shift, fused: one rounding), v_pk_mul_f16 + v_pk_max_f16 (LeakyReLU) - 12 VALU per piece.
+    // The kernel is VALU-bound with this work in it (two waves per SIMD: SQ counters), so every instruction
+    // counts: scale and shift are held as fp16 (that rounds them to 2^-11 relative, the precision of the activation
+    // itself), and out-of-volume pieces are not selected to zero here but overwritten in LDS by a second, masked write.
+    auto in_affine = [&](f32x4 raw, f16x8 sc, f16x8 sh, half_t slope_h) {
+        f16x8 y = __builtin_elementwise_fma(__builtin_bit_cast(f16x8, raw), sc, sh);
+        const f16x8 sl8 = {slope_h, slope_h, slope_h, slope_h, slope_h, slope_h, slope_h, slope_h};
         y = __builtin_elementwise_max(y, y * sl8);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        return inside ? __builtin_bit_cast(f32x4, y) : z;
+        return __builtin_bit_cast(f32x4, y);
     };
     const float slope_in = p.in_act == ACT_LRELU ? p.slope : 1.0f;
     // per-(sample, channel) scale / shift of the 8 channels this thread stages in chunk `ch` of sample n (in0 only: the
@@ -514,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
             sc[j] = from_in0 ? (half_t)s0[j] : (half_t)1.f; sc[4 + j] = from_in0 ? (half_t)s1[j] : (half_t)1.f;
             sh[j] = from_in0 ? (half_t)h0[j] : (half_t)0.f; sh[4 + j] = from_in0 ? (half_t)h1[j] : (half_t)0.f;
         }
-        return from_in0 ? slope_in : 1.0f;
+        return (half_t)(from_in0 ? slope_in : 1.0f);
     };
 
     f32x16 acc[MF][NF];
@@ -535,13 +530,18 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
     TileCoord cur = decode(tile);
     {
         f16x8 sc0, sh0;
-        float sl0 = 1.f;
+        half_t sl0 = (half_t)1.f;
         if constexpr (INAFF) sl0 = load_aff(cur.n, 0, sc0, sh0);
 #pragma unroll
         for (int r = 0; r < SLOTS; ++r) {
             f32x4 v = stage_issue(cur, tile_faces(cur), tile_ragged(cur), 0, r);
-            if constexpr (INAFF) v = in_affine(v, sc0, sh0, sl0, slot_inside(cur, tile_faces(cur), tile_ragged(cur), r));
-            if (slot_valid(r)) *(f32x4 *)(lds_raw + dst0 + r * 2048) = v;
+            if constexpr (INAFF) v = in_affine(v, sc0, sh0, sl0);
+            if (slot_valid(r)) {
+                *(f32x4 *)(lds_raw + dst0 + r * 2048) = v;
+                if constexpr (INAFF) {  // padding follows the norm: out-of-volume pieces are zero, not act(shift)
+                    if (!slot_inside(cur, tile_faces(cur), tile_ragged(cur), r)) *(f32x4 *)(lds_raw + dst0 + r * 2048) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
         }
     }
     f16x8 bq[BD][NF];
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         for (int mf = 0; mf < MF; ++mf) a[0][mf] = *(lds_cf16x8 *)(ab[mf]);
         f32x4 st_v[SLOTS];
         f16x8 sc_n, sh_n;  // INAFF: scale / shift of the chunk being staged (loaded with the first fetch, used FLIGHT taps later)
-        float sl_n = 1.f;
+        half_t sl_n = (half_t)1.f;
         if constexpr (INAFF) sl_n = load_aff(nxt.n, nch_eff, sc_n, sh_n);
 
         // (compile-time tap and slot indices: a "#pragma unroll" the optimiser declines turns a[tap & 1], bq[tap % BD] and
@@ -617,8 +617,11 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
                 constexpr int wr = r + FLIGHT < 26 ? r + FLIGHT : 26;
                 if constexpr (wr == tap) {
                     if (have_next && slot_valid(r)) {
-                        if constexpr (INAFF) st_v[r] = in_affine(st_v[r], sc_n, sh_n, sl_n, slot_inside(nxt, nfaces, nragged, r));
+                        if constexpr (INAFF) st_v[r] = in_affine(st_v[r], sc_n, sh_n, sl_n);
                         *(f32x4 *)(bufn + dst0 + r * 2048) = st_v[r];
+                        if constexpr (INAFF) {  // (second write, same wave, in order: zero where the piece lies outside the volume)
+                            if (!slot_inside(nxt, nfaces, nragged, r)) *(f32x4 *)(bufn + dst0 + r * 2048) = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
                     }
                 }
             });
