@@ -9,9 +9,11 @@
 //   * LDS image of the input brick is planar [8-channel half][brick voxel][16 B]: x-consecutive lanes
 //     read consecutive 16-B slots (conflict-free ds_read_b128), 32 B per voxel and chunk;
 //   * weights are packed on the host as [cout block][chunk][tap][nf][lane][8 halfs] (1 KiB fragments).
-// Kernels: conv3_f16_mfma_pipe_kernel (stride 1: persistent, double-buffered brick staged through a buffer descriptor
-// while the 27 tap steps of the previous chunk run; HEAD variant applies the 1x1x1 head with four extra MFMAs),
-// conv3_f16_s2dma_kernel (stride 2, large launches: LDS-DMA bricks + weight planes through LDS), and the simple
+// Kernels: conv3_f16_dma_kernel (stride 1, Cout % 64 == 0, volumes that are whole 8^3 tiles: one wave per SIMD, brick by
+// LDS-DMA, weights in a hand-waited register ring, whole-line stores), conv3_f16_mfma_pipe_kernel (the other stride-1
+// launches: persistent, double-buffered brick staged through a buffer descriptor while the 27 tap steps of the previous
+// chunk run; INAFF variant applies the producer's normalisation while staging, HEAD variant the 1x1x1 head with four
+// extra MFMAs; its STRIDE = 2 instantiation with 128-output tiles serves the large stride-2 launches), and the simple
 // conv3_f16_mfma_kernel (one tile per workgroup, stride 1|2; also the split-K slices of the deep levels, finished by
 // splitk_finish_f16_kernel).
 #include "kernels.h"
@@ -43,9 +45,9 @@ struct ConvArgsH {
     const float *head_w, *head_b;  // fused 1x1x1 head (see ConvCall)
     float *head_out;
     int head_ncls;
-    TileOrder order;  // blocked tile order of the persistent stride-2 kernel (common.h)
     int plane_bytes;  // brickvox * 16
-    const void *zeros;  // >= 32 B of zeros in global memory (stride-2 DMA kernel: source of out-of-volume pieces)
+    const void *zeros;  // >= 32 B of zeros in global memory (LDS-DMA kernel: the source of out-of-volume pieces)
+    TileOrder order;    // blocked tile order of the LDS-DMA kernel (common.h)
     // split-K (simple kernel, small launches): blockIdx.z = slice of the channel chunks; fp32 partial sums go to `partial`
     int ksplit;
     float *partial;
@@ -84,7 +86,9 @@ __device__ __forceinline__ void store_f16x4(half_t *ptr, f16x4 v) {
     else *(f16x4 *)ptr = v;
 }
 
-template <int MF, int NF, bool HEAD = false, bool SC1 = false>
+// PATH: -1 = statistics iff p.stats (runtime), 0 = never, 1 = always (conv3_f16_dma_kernel: with both paths inlined behind
+// its 72-register weight ring the allocator spills)
+template <int MF, int NF, bool HEAD = false, bool SC1 = false, int PATH = -1>
 __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const ConvArgsH &p, int n, int oz0, int oy0,
                                                   int ox0, int co_blk, float *red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -142,7 +146,7 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
         }
         return;
     }
-    if (!p.stats) {
+    if (PATH == 0 || (PATH < 0 && !p.stats)) {
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
             const int v = (wave * MF + mf) * 32 + l31;
@@ -363,10 +367,14 @@ __global__ __launch_bounds__(256) void splitk_finish_f16_kernel(const float *par
 }
 
 // ------------------------------------------------------------------ pipelined persistent kernel (stride 1)
-template <int MF, int NF, bool HEAD = false, bool INAFF = false>
+// STRIDE = 2 (round 2): the same kernel on the encoder's stride-2 convs with 128-output tiles (MF = 1).  Its staging fetches
+// the 32 contiguous bytes of a voxel's chunk with two adjacent lanes, so an instruction touches half the 128-B lines that
+// the LDS-DMA stride-2 kernel's plane-wise 16-B pieces touch - and the line rate of the L1, not the matrix pipe or the
+// L2, is what held that kernel at 0.13-0.16 of the fp16 peak.
+template <int MF, int NF, bool HEAD = false, bool INAFF = false, int STRIDE = 1>
 __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    constexpr int SLOTS = MF == 4 ? 11 : 8;  // 16-B staging pieces per thread and chunk
+    constexpr int SLOTS = STRIDE == 2 ? 13 : (MF == 4 ? 11 : 8);  // 16-B staging pieces per thread and chunk
     constexpr int BD = 3;                    // weight fragments fetched BD tap-steps ahead; the ring phase must
                                              // be the same in every chunk, so BD divides 27
     constexpr int FLIGHT = 7;               // tap-steps between a staging fetch and its LDS write
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
     for (int mf = 0; mf < MF; ++mf) {
         const int v = (wave * MF + mf) * 32 + l31;
         const int x = v & TXm, y = (v >> p.lx) & TYm, z = v >> (p.lx + p.ly);
-        a_base[mf] = half * p.plane_bytes + ((z * IY + y) * IX + x) * 16;
+        a_base[mf] = half * p.plane_bytes + ((z * STRIDE * IY + y * STRIDE) * IX + x * STRIDE) * 16;
     }
     const int qoff = (tid & 1) * 8;
 
@@ -434,11 +442,14 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
     auto tile_faces = [&](const TileCoord &tc) {
         // a brick spans [o0-1, o0+T+1): the low face is outside iff o0 == 0, the high face iff o0 + T >= dim.
         // voxels beyond the high face + 1 (tiles overhanging a ragged volume) are caught by the exact test below.
-        return (tc.oz0 == 0) | ((tc.oz0 + (1 << p.lz) >= p.Di) << 1) | ((tc.oy0 == 0) << 2) |
-               ((tc.oy0 + (1 << p.ly) >= p.Hi) << 3) | ((tc.ox0 == 0) << 4) | ((tc.ox0 + (1 << p.lx) >= p.Wi) << 5);
+        // (stride S: the brick's last input voxel is S (o0 + T - 1) + 1)
+        return (tc.oz0 == 0) | ((STRIDE * (tc.oz0 + (1 << p.lz) - 1) + 1 >= p.Di) << 1) | ((tc.oy0 == 0) << 2) |
+               ((STRIDE * (tc.oy0 + (1 << p.ly) - 1) + 1 >= p.Hi) << 3) | ((tc.ox0 == 0) << 4) |
+               ((STRIDE * (tc.ox0 + (1 << p.lx) - 1) + 1 >= p.Wi) << 5);
     };
     auto tile_ragged = [&](const TileCoord &tc) {
-        return (tc.oz0 + (1 << p.lz) > p.Di) | (tc.oy0 + (1 << p.ly) > p.Hi) | (tc.ox0 + (1 << p.lx) > p.Wi);
+        return (STRIDE * (tc.oz0 + (1 << p.lz) - 1) + 1 > p.Di) | (STRIDE * (tc.oy0 + (1 << p.ly) - 1) + 1 > p.Hi) |
+               (STRIDE * (tc.ox0 + (1 << p.lx) - 1) + 1 > p.Wi);
     };
     const int dst0 = (tid & 1) * p.plane_bytes + (tid >> 1) * 16;  // LDS byte offset of slot 0; slot r is 128 voxels further
     auto stage_issue = [&](const TileCoord &tc, int faces, bool ragged, int ch, int r) {
@@ -454,12 +465,12 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
             const int bx = bv - rr * IX;
             const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
             const int by = rr - bz * IY;
-            inside = ((pk >> 30) == 0) && ((unsigned)(tc.oz0 - 1 + bz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + by) < (unsigned)p.Hi) &&
-                     ((unsigned)(tc.ox0 - 1 + bx) < (unsigned)p.Wi);
+            inside = ((pk >> 30) == 0) && ((unsigned)(STRIDE * tc.oz0 - 1 + bz) < (unsigned)p.Di) && ((unsigned)(STRIDE * tc.oy0 - 1 + by) < (unsigned)p.Hi) &&
+                     ((unsigned)(STRIDE * tc.ox0 - 1 + bx) < (unsigned)p.Wi);
         }
         // wave-uniform descriptor based at the brick origin voxel (may lie one voxel outside the tensor: only pieces
         // inside the volume are addressed through it)
-        const long base_vox = (((long)tc.n * p.Di + (tc.oz0 - 1)) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1);
+        const long base_vox = (((long)tc.n * p.Di + (STRIDE * tc.oz0 - 1)) * p.Hi + (STRIDE * tc.oy0 - 1)) * p.Wi + (STRIDE * tc.ox0 - 1);
         const half_t *sbase = src + base_vox * Csrc + coff;
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sbase, 0, 0x7fffffff, 0x00020000);
         const unsigned off = __umul24((unsigned)pk & 0xffffffu, (unsigned)(Csrc * 2)) + qoff * 2;
@@ -479,8 +490,8 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
             const int bx = bv - rr * IX;
             const int bz = (int)fdiv((uint32_t)rr, p.div_IY);
             const int by = rr - bz * IY;
-            inside = ((pk >> 30) == 0) && ((unsigned)(tc.oz0 - 1 + bz) < (unsigned)p.Di) && ((unsigned)(tc.oy0 - 1 + by) < (unsigned)p.Hi) &&
-                     ((unsigned)(tc.ox0 - 1 + bx) < (unsigned)p.Wi);
+            inside = ((pk >> 30) == 0) && ((unsigned)(STRIDE * tc.oz0 - 1 + bz) < (unsigned)p.Di) && ((unsigned)(STRIDE * tc.oy0 - 1 + by) < (unsigned)p.Hi) &&
+                     ((unsigned)(STRIDE * tc.ox0 - 1 + bx) < (unsigned)p.Wi);
         }
         return inside;
     };
@@ -638,32 +649,70 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
     }
 }
 
-// ------------------------------------------------------------------ stride 2: persistent LDS-DMA kernel
-// fp16 twin of conv3_f32_s2dma_kernel (conv3d.hip): one persistent workgroup per CU, the 16-channel halo brick
-// (2 planes of 16-B pieces) double-buffered and filled by LDS-DMA, the weights of one dz plane (9 taps x 64 couts =
-// 18 KiB) per step through a two-slot LDS ring shared by the four waves.  Per tap a wave reads one voxel fragment and
-// two weight fragments from LDS and issues two MFMAs: 3 KiB per 64 matrix cycles per wave - the kernel is bound by the
-// LDS (192 B/clk asked of 128), which is still three times what per-wave weight streaming through the L1 delivered.
-template <int TXL>
-struct S2GeomH {
-    static constexpr int TX = 1 << TXL, TY = 64 >> TXL;
-    static constexpr int IX = 2 * TX + 1, IY = 2 * TY + 1, IZ = 5, BV = IX * IY * IZ;
-    static constexpr int RSTRIDE = (BV - 64 + 26) / 27;      // 28 DMA ranges [RSTRIDE*r, +64) per plane
-    static constexpr int PAD = 27 * RSTRIDE + 64 - BV;
-    static constexpr int BUF_BYTES = (2 * BV + PAD) * 16;
-    static constexpr int WSLOT_BYTES = 9 * 2 * 1024;
-    static constexpr size_t LDS_BYTES = (size_t)2 * BUF_BYTES + 2 * WSLOT_BYTES + 4 * 64 * 2 * sizeof(float);
+// ------------------------------------------------------------------ stride 1, Cout % 64 == 0: LDS-DMA kernel (round 2)
+// The pipelined kernel above spends a quarter of its time on the staging of the brick (ablation: -26 % without it):
+// per piece a buffer load into a register, five VALU instructions and a ds_write, all of it issued between MFMAs that
+// are only 32 cycles long in fp16.  This kernel is conv3_f32_wino2_kernel's skeleton (conv3d.hip) applied to the direct
+// fp16 conv: ONE wave per SIMD that owns 128 voxels x 64 couts (8 MFMAs per tap, 128 accumulators in AGPRs), the
+// 10 x 10 x 10 halo brick of an 8 x 8 x 8 tile double-buffered in LDS and filled by LDS-DMA (no staging registers, no
+// ds_write; ~8 VALU per DMA for the address), the weights in a nine-tap register ring fetched with inline-asm loads and
+// hand-counted waits (while an LDS-DMA is in flight hipcc retires EVERY vector-memory operation before the first use of
+// an ordinary load).  All 27 tap offsets are instruction immediates (the brick geometry is a compile-time constant).
+//   vmcnt bookkeeping (loads return in order; stores only make a count more conservative): tap t = [wait for W(t)]
+//   [2 MFMAs] [LDS reads of tap t+1] [a DMA in every third tap] [6 MFMAs] [2 loads W(t+9) into the ring slot just consumed].
+//   The loads issued after W(t) are those of taps t-8 .. t-1: 16 + the DMAs among them (DmaGeomH::pending); after the last
+//   DMA of a chunk come the weight loads of the remaining taps, and that many may be outstanding at the barrier that
+//   publishes the brick.
+#ifdef MI355_H16_STAMPS
+// tools/h16_probe.hip: cycle sums of wave 0 per workgroup. 0 taps 0-8, 1 taps 9-17, 2 taps 18-26, 3 drain + barrier, 4 epilogue,
+// 5 whole kernel, 6 chunks, 7 tiles, 8 accumulator init + set-up
+__device__ unsigned long long h16_stamps[1024 * 16];
+#define H16_T(v) unsigned long long v = 0; if (stamp_on) v = __builtin_readcyclecounter()
+#define H16_ACC(k, a, b) if (stamp_on) h16_acc[k] += (b) - (a)
+#else
+#define H16_T(v)
+#define H16_ACC(k, a, b)
+#endif
+struct DmaGeomH {
+    static constexpr int IX = 10, IY = 10, IZ = 10, BV = IX * IY * IZ;
+    static constexpr int PLANE_SLOTS = 1024, PLANE_BYTES = PLANE_SLOTS * 16, BUF_BYTES = 2 * PLANE_BYTES;
+    static constexpr int D = 9;    // weight ring depth in taps (divides 27: the ring phase is the same in every chunk)
+    static constexpr int KD = 8;   // DMAs per wave and chunk: range wave + 4 (k & 3) of plane k >> 2
+#ifndef MI355_H16_DMA_EVERY
+#define MI355_H16_DMA_EVERY 3
+#endif
+    static constexpr int EVERY = MI355_H16_DMA_EVERY;  // DMA k goes out in tap EVERY * k: four waves issuing 64-line DMAs in the same
+                                                       // tap ask the L1 for more lines than a tap has cycles (stamps: +1.3-2.2k per chunk)
+    static constexpr bool dma_tap(int t) { return t % EVERY == 0 && t / EVERY < KD; }
+    // loads issued after the weight loads of tap t (which went out at the end of tap t - D): two per tap of taps t-8 .. t-1
+    // and the DMAs among those taps (taps < 0 are the previous chunk's)
+    static constexpr int pending(int t) {
+        int n = 2 * (D - 1);
+        for (int j = t - (D - 1); j <= t - 1; ++j) n += dma_tap((j + 27) % 27) ? 1 : 0;
+        return n;
+    }
+    // weight loads issued after the chunk's last DMA
+    static constexpr int after_last_dma = 2 * (27 - EVERY * (KD - 1));
+    // epilogue: each wave transposes its 128 voxels x 64 couts through a private LDS image (row = voxel, 144-B pitch: the
+    // 8-B writes of 32 consecutive voxels spread over all banks) and stores whole 128-B lines
+    static constexpr int EPI_PITCH = 144, EPI_WAVE_BYTES = 128 * EPI_PITCH;
+    static constexpr int RED_OFF = 2 * BUF_BYTES, BIAS_OFF = RED_OFF + 4 * 64 * 2 * 4, EPI_OFF = BIAS_OFF + 64 * 4;
+    static constexpr size_t LDS_BYTES = (size_t)EPI_OFF + 4 * EPI_WAVE_BYTES;
 };
 
-template <int TXL>
-__global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(ConvArgsH p) {
+template <bool STATS>
+__global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    typedef S2GeomH<TXL> GM;
-    constexpr int IX = GM::IX, IY = GM::IY, BV = GM::BV;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    char *wring = lds_raw + 2 * GM::BUF_BYTES;
-    float *red = (float *)(wring + 2 * GM::WSLOT_BYTES);
+    typedef DmaGeomH G;
+    constexpr int MF = 4, NF = 2;
+    constexpr int IX = G::IX, IY = G::IY;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *red = (float *)(lds_raw + G::RED_OFF);
+    float *bias_lds = (float *)(lds_raw + G::BIAS_OFF);
+    if (tid < 64) bias_lds[tid] = p.bias[(int)blockIdx.y * NF * 32 + tid];  // (published by the prologue's barrier)
 
+    // this workgroup's tile sequence: XCD group x owns the contiguous range [lo, hi); its workgroups stride through it
     const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
     const int nl = ((int)gridDim.x - xcd + 7) >> 3;
     const int q8 = p.total_tiles >> 3, r8 = p.total_tiles & 7;
@@ -679,115 +728,294 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(ConvArgsH p) {
         const int tt = t - tc.n * (int)p.div_tiles_per_n.d;
         int tile_x, tile_y, tile_z;
         tile_from_id(tt, p.order, tile_x, tile_y, tile_z);
-        tc.oz0 = tile_z << 1; tc.oy0 = tile_y * GM::TY; tc.ox0 = tile_x << TXL;
+        tc.oz0 = tile_z << 3; tc.oy0 = tile_y << 3; tc.ox0 = tile_x << 3;
         return tc;
     };
+    // which faces of the brick [o0 - 1, o0 + 8] stick out of the volume (bit 0/1: z lo/hi, 2/3: y, 4/5: x); the volume is a
+    // whole number of tiles (host check), so nothing else of a brick can lie outside
+    auto tile_faces = [&](const TileCoord &tc) {
+        return (tc.oz0 == 0) | ((tc.oz0 + 8 >= p.Di) << 1) | ((tc.oy0 == 0) << 2) | ((tc.oy0 + 8 >= p.Hi) << 3) |
+               ((tc.ox0 == 0) << 4) | ((tc.ox0 + 8 >= p.Wi) << 5);
+    };
 
-    unsigned dma_pk[7];
+    // tile-invariant lane part of the four DMA ranges of a plane: voxel offset from the brick origin (24 bits) | the
+    // brick faces the voxel lies on << 24 (bit 6: a padding slot beyond the brick)
+    unsigned dma_pk[4];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        int bv = (wave + 4 * k) * GM::RSTRIDE + lane;
-        const int over = bv >= BV ? 1 : 0;
-        bv -= over * BV;
-        const int rr = bv / IX, bx = bv - rr * IX;
-        const int rz = rr / IY, ry = rr - rz * IY;
-        dma_pk[k] = (unsigned)(rz | (ry << 4) | (bx << 8) | (over << 16));
+    for (int k = 0; k < 4; ++k) {
+        const int bv = (wave + 4 * k) * 64 + lane;
+        const int bz = bv / (IX * IY), rr = bv - bz * (IX * IY), by = rr / IX, bx = rr - by * IX;
+        const int face = (bz == 0) | ((bz == G::IZ - 1) << 1) | ((by == 0) << 2) | ((by == IY - 1) << 3) | ((bx == 0) << 4) | ((bx == IX - 1) << 5);
+        dma_pk[k] = bv < G::BV ? (unsigned)(((bz * p.Hi + by) * p.Wi + bx) | (face << 24)) : (64u << 24);
     }
-    auto dma_brick = [&](const TileCoord &tc, int ch, int k, char *buf) {
-        const int rng = wave + 4 * k;
+    auto dma = [&](const TileCoord &tc, int faces, int ch, auto k_c, char *buf) {
+        constexpr int k = decltype(k_c)::value;
         const int cglob = ch * 16;
         const half_t *src; int Csrc, coff;
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
-        src += ((((size_t)tc.n * p.Di + (2 * tc.oz0 - 1)) * p.Hi + (2 * tc.oy0 - 1)) * p.Wi + (2 * tc.ox0 - 1)) * (long)Csrc + coff;
-        const unsigned pk = dma_pk[k];
-        const int rz = pk & 15, ry = (pk >> 4) & 15, bx = (pk >> 8) & 255, over = pk >> 16;
-        const bool in_vol = ((unsigned)(2 * tc.oz0 - 1 + rz) < (unsigned)p.Di) && ((unsigned)(2 * tc.oy0 - 1 + ry) < (unsigned)p.Hi) &&
-                            ((unsigned)(2 * tc.ox0 - 1 + bx) < (unsigned)p.Wi);
-        const int voff = ((rz * p.Hi + ry) * p.Wi + bx) * Csrc + over * 8;  // halfs
-        const half_t *g0 = in_vol ? src + voff : (const half_t *)p.zeros;
-        const half_t *g1 = (in_vol && over == 0) ? src + voff : (const half_t *)p.zeros;  // plane 1's overrun lanes fill padding
-        asm volatile("" : "+v"(g0), "+v"(g1));
-        char *dst = buf + rng * GM::RSTRIDE * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g0,
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g1,
-                                         (__attribute__((address_space(3))) void *)(dst + BV * 16 - 16), 16, 16, 0);
+        // wave-uniform part (SALU): the brick origin voxel, which may lie one voxel outside the tensor
+        src += ((((long)tc.n * p.Di + (tc.oz0 - 1)) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1)) * (long)Csrc + coff;
+        unsigned pk = dma_pk[k & 3];
+        asm volatile("" : "+v"(pk));
+        bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
+        unsigned off = __umul24(pk & 0xffffffu, (unsigned)(Csrc * 2));  // bytes (< 2^32: host check)
+        const char *gin = (const char *)src + off;
+        asm volatile("" : "+v"(gin));  // (computed for every lane: left to itself the compiler branches around it, and a basic-block
+                                       //  boundary between the MFMAs of a tap makes it wait for every outstanding LDS read there)
+        const char *g = inside ? gin : (const char *)p.zeros;  // the zero page holds both planes' pieces
+        asm volatile("" : "+v"(g));
+        // plane 1 = channels 8..15: the instruction's immediate is added to the global AND the LDS address
+        char *dst = buf + (k >> 2) * G::PLANE_BYTES + (wave + 4 * (k & 3)) * 1024 - (k >> 2) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst,
+                                         16, (k >> 2) * 16, 0);
     };
-    const char *wblk = (const char *)(p.wp + (size_t)blockIdx.y * p.nchunks * (27 * 2 * 512));
-    auto dma_weights = [&](int ch, int dz, char *slot) {
-        const char *wsrc = wblk + ((size_t)ch * 27 + dz * 9) * 2048 + lane * 16;
+
+    // LDS byte offsets of this lane's voxel fragments in a brick buffer (tap (0,0,0)); fragment mf of wave w holds the
+    // voxels v = (4 w + mf) * 32 + l31 of the tile: x = v & 7, y = (v >> 3) & 7, z = v >> 6
+    int a_base[MF];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int kib = wave + 4 * i;
-            if (kib < 18)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + kib * 1024),
-                                                 (__attribute__((address_space(3))) void *)(slot + kib * 1024), 16, 0, 0);
-        }
-    };
+    for (int mf = 0; mf < MF; ++mf) {
+        const int v = (wave * MF + mf) * 32 + l31;
+        a_base[mf] = half * G::PLANE_BYTES + (((v >> 6) * IY + ((v >> 3) & 7)) * IX + (v & 7)) * 16;
+    }
+    const int co_blk = (int)blockIdx.y * NF * 32;
+    const char *wblk = (const char *)(p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512));
+    const unsigned wlane = lane * 16;
+#define H16_WLOAD(DST, SBASE, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(DST) : "v"(wl), "s"(SBASE), "n"(IMM) : "memory")
+#define H16_WWAIT(W, N) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(W[0]), "+v"(W[1]) : "n"(N) : "memory")
 
-    const int ay = (wave & 1) * (GM::TY / 2) + (l31 >> TXL), ax = l31 & (GM::TX - 1);
-    const int a_base = half * BV * 16 + (((wave >> 1) * 2 * IY + ay * 2) * IX + 2 * ax) * 16;  // bytes
-    const int co_blk = (int)blockIdx.y * 64;
-
+#ifdef MI355_H16_STAMPS
+    const bool stamp_on = tid == 0 && blockIdx.y == 0;
+    unsigned long long h16_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    H16_T(t_k0);
     TileCoord cur = decode(tile);
-#pragma unroll
-    for (int k = 0; k < 7; ++k) dma_brick(cur, 0, k, lds_raw);
-    dma_weights(0, 0, wring);
-    __syncthreads();
+    f16x8 wq[G::D][NF];
+    {
+        const int f0 = tile_faces(cur);
+        static_for<0, G::KD>([&](auto k_c) { dma(cur, f0, 0, k_c, lds_raw); });
+        static_for<0, G::D>([&](auto t_c) {
+            constexpr int t = decltype(t_c)::value;
+            const char *wb = wblk + t * (NF * 1024);
+            const unsigned wl = wlane;  // (asm operands alone do not capture)
+            auto &w = wq[t];
+            H16_WLOAD(w[0], wb, 0);
+            H16_WLOAD(w[1], wb, 1024);
+        });
+        // (the ring registers are operands of the wait: the compiler must not read or move them before it)
+        static_for<0, G::D>([&](auto t_c) { auto &w = wq[decltype(t_c)::value]; H16_WWAIT(w, 0); });
+        __syncthreads();
+    }
 
-    int buf = 0, wslot = 0;
+    int buf = 0;
     for (; tile < hi; tile += nl) {
-        f32x16 acc[1][2];
-        acc_init_bias<1, 2>(acc, p.bias, co_blk, half);
+        H16_T(t_t0);
+        f32x16 acc[MF][NF];
+        {   // bias from LDS (a global load here is an L2 round trip per tile with nothing to hide it behind)
+            typedef const __attribute__((address_space(3))) f32x4 lds_cf32x4;
+            unsigned bl = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)bias_lds + half * 16;
+            asm volatile("" : "+v"(bl));  // (the reads stay inside the tile loop: hoisted they are 32 live registers)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b = *(lds_cf32x4 *)(bl + (nf * 32 + 8 * g) * 4);
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[mf][nf][4 * g + k] = b[k];
+                }
+        }
         const int ntile = tile + nl;
         const TileCoord nxt_tile = ntile < hi ? decode(ntile) : cur;
+#ifdef MI355_H16_STAMPS
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) asm volatile("" : "+a"(acc[mf][nf]));
+#endif
+        H16_T(t_t1);
+        H16_ACC(8, t_t0, t_t1);
         for (int ch = 0; ch < p.nchunks; ++ch) {
+            H16_T(t_c0);
             const bool last_ch = ch == p.nchunks - 1;
             const bool have_next = !last_ch || ntile < hi;
             const TileCoord nxt = last_ch ? nxt_tile : cur;
-            const int nch = last_ch ? 0 : ch + 1;
-            const char *bufc = lds_raw + buf * GM::BUF_BYTES;
-            char *bufn = lds_raw + (buf ^ 1) * GM::BUF_BYTES;
+            // (without a next chunk the DMAs re-stage the current one into the idle buffer: the wait counts stay fixed)
+            const int nch_eff = have_next ? (last_ch ? 0 : ch + 1) : ch;
+            const int nfaces = tile_faces(nxt);
+            const char *bufc = lds_raw + buf * G::BUF_BYTES;
+            char *bufn = lds_raw + (buf ^ 1) * G::BUF_BYTES;
+            const char *wch = wblk + (size_t)ch * (27 * NF * 1024), *wnx = wblk + (size_t)nch_eff * (27 * NF * 1024);
+
+            typedef const __attribute__((address_space(3))) char lds_cchar;
+            typedef const __attribute__((address_space(3))) f16x8 lds_cf16x8;
+            lds_cchar *ab[MF];
 #pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {
-                if (dz < 2) dma_weights(ch, dz + 1, wring + (wslot ^ 1) * GM::WSLOT_BYTES);
-                else if (have_next) dma_weights(nch, 0, wring + (wslot ^ 1) * GM::WSLOT_BYTES);
-                if (have_next) {
-                    if (dz == 0) { dma_brick(nxt, nch, 0, bufn); dma_brick(nxt, nch, 1, bufn); dma_brick(nxt, nch, 2, bufn); }
-                    else if (dz == 1) { dma_brick(nxt, nch, 3, bufn); dma_brick(nxt, nch, 4, bufn); }
-                    else { dma_brick(nxt, nch, 5, bufn); dma_brick(nxt, nch, 6, bufn); }
-                }
-                const char *wcur = wring + wslot * GM::WSLOT_BYTES + lane * 16;
-                f16x8 a_cur, a_nxt, b_cur[2], b_nxt[2];
-                a_cur = *(const f16x8 *)(bufc + a_base + dz * IY * IX * 16);
-                b_cur[0] = *(const f16x8 *)(wcur);
-                b_cur[1] = *(const f16x8 *)(wcur + 1024);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    if (t + 1 < 9) {
-                        const int dy = (t + 1) / 3, dx = (t + 1) - dy * 3;
-                        a_nxt = *(const f16x8 *)(bufc + a_base + ((dz * IY + dy) * IX + dx) * 16);
-                        b_nxt[0] = *(const f16x8 *)(wcur + (t + 1) * 2048);
-                        b_nxt[1] = *(const f16x8 *)(wcur + (t + 1) * 2048 + 1024);
-                    }
-#pragma unroll
-                    for (int nf = 0; nf < 2; ++nf)
-                        acc[0][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_cur[nf], a_cur, acc[0][nf], 0, 0, 0);
-                    a_cur = a_nxt; b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier
-                __syncthreads();  // retires the step's DMAs (vmcnt(0)); the other weight slot / brick buffer may be read now
-                wslot ^= 1;
+            for (int mf = 0; mf < MF; ++mf) {
+                unsigned t = (unsigned)(size_t)(lds_cchar *)bufc + a_base[mf];
+                asm volatile("" : "+v"(t));
+                ab[mf] = (lds_cchar *)t;
             }
+            f16x8 a[2][MF];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) a[0][mf] = *(lds_cf16x8 *)(ab[mf]);
+
+#ifdef MI355_H16_STAMPS
+            unsigned long long t_seg = t_c0;
+#endif
+            static_for<0, 27>([&](auto tap_c) {
+                constexpr int tap = decltype(tap_c)::value;
+                constexpr int slot = tap % G::D;
+                constexpr int pending = G::pending(tap);
+                auto &wc = wq[slot];
+                H16_WWAIT(wc, pending);
+                // the first MFMAs go out before the tap's memory instructions: the compiler waits for ALL outstanding LDS
+                // reads before the first MFMA of a tap (lgkmcnt(0): it will not count past an LDS-DMA), so the reads of tap
+                // t+1 are issued behind two MFMAs of tap t and are a tap old when that wait comes
+                static_for<0, 8>([&](auto i_c) {
+                    constexpr int i = decltype(i_c)::value;
+                    constexpr int mf = i >> 1, nf = i & 1;
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[slot][nf], a[tap & 1][mf], acc[mf][nf], 0, 0, 0);
+                    if constexpr (i == 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (tap + 1 < 27) {
+                            constexpr int nt = tap + 1;
+                            constexpr int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
+                            constexpr int off = ((dz * IY + dy) * IX + dx) * 16;
+#pragma unroll
+                            for (int m = 0; m < MF; ++m) a[(tap + 1) & 1][m] = *(lds_cf16x8 *)(ab[m] + off);
+                        }
+                        if constexpr (G::dma_tap(tap)) dma(nxt, nfaces, nch_eff, std::integral_constant<int, tap / G::EVERY>{}, bufn);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    constexpr int k = tap + G::D;
+                    const char *wb = (k < 27) ? wch + k * (NF * 1024) : wnx + (k - 27) * (NF * 1024);
+                    const unsigned wl = wlane;
+                    H16_WLOAD(wc[0], wb, 0);
+                    H16_WLOAD(wc[1], wb, 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef MI355_H16_STAMPS
+                if constexpr (tap == 8 || tap == 17 || tap == 26) {
+                    if (stamp_on) { const unsigned long long t = __builtin_readcyclecounter(); h16_acc[tap / 9] += t - t_seg; t_seg = t; }
+                }
+#endif
+            });
+            // this wave's DMAs have landed once at most the 40 weight loads issued after DMA 7 are outstanding; the barrier
+            // publishes the brick (a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier)
+            H16_T(t_c2);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::after_last_dma) : "memory");
+            __builtin_amdgcn_s_barrier();
             buf ^= 1;
+            H16_T(t_c3);
+            H16_ACC(3, t_c2, t_c3);
+#ifdef MI355_H16_STAMPS
+            if (stamp_on) h16_acc[6] += 1;
+#endif
         }
-        ConvArgsH q = p;
-        q.lx = TXL; q.ly = 6 - TXL; q.lz = 1;  // voxel v = wave * 32 + lane: x = v & (TX-1), y = (v >> TXL) & (TY-1), z = v >> 6
-        conv_epilogue_f16<1, 2>(acc, q, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red);  // (8-B sc1 stores cost 2.7x per byte: not here)
-        if (p.stats) __syncthreads();  // the statistics scratch is reused by the next tile
+        H16_T(t_e0);
+        // The ring already holds the next tile's first nine taps, still in flight.  The compiler knows nothing of that: if it
+        // moved one of those registers during the epilogue (a spill copy to an AGPR) it would copy what was there BEFORE the
+        // load landed.  So the loads are retired here, with the ring as operands of the wait.
+        static_for<0, G::D>([&](auto t_c) { auto &w = wq[decltype(t_c)::value]; H16_WWAIT(w, 0); });
+        {
+            // ---- epilogue: LeakyReLU + fp16 in registers, transposed through this wave's LDS image, whole-line stores
+            typedef __attribute__((address_space(3))) char lds_char;
+            const float slope = p.act == ACT_LRELU ? p.slope : 1.0f;  // max(x, 1*x) = x
+            unsigned img = (unsigned)(size_t)(lds_char *)(lds_raw + G::EPI_OFF) + wave * G::EPI_WAVE_BYTES;
+            unsigned wr = img + l31 * G::EPI_PITCH + half * 8;
+            asm volatile("" : "+v"(wr));
+            // (cout fragment outermost: the statistics of one fragment are 32 live registers, not 64)
+            static_for<0, NF>([&](auto nf_c) {
+                constexpr int nf = decltype(nf_c)::value;
+                float s1[16], s2[16];
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+                }
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        const f32x2 slope2 = {slope, slope};
+                        f16x4 val;
+#pragma unroll
+                        for (int k = 0; k < 4; k += 2) {
+                            const f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
+                            f32x2 y;
+                            float m0, m1;
+                            asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(x[0]), "v"(y[0]));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(x[1]), "v"(y[1]));
+                            val[k] = (half_t)m0;
+                            val[k + 1] = (half_t)m1;
+                            if constexpr (STATS) {
+                                s1[4 * g + k] += m0; s2[4 * g + k] += m0 * m0;
+                                s1[4 * g + k + 1] += m1; s2[4 * g + k + 1] += m1 * m1;
+                            }
+                        }
+                        *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + (nf * 32 + 8 * g) * 2) = val;
+                    }
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float a = s1[r], b = s2[r];
+#pragma unroll
+                        for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+                        if (l31 == 0) {
+                            const int c = nf * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            red[(wave * NF * 32 + c) * 2 + 0] = a;
+                            red[(wave * NF * 32 + c) * 2 + 1] = b;
+                        }
+                    }
+                }
+            });
+            // rows 8 j .. 8 j + 7 of the image are the x-row (z = 2 wave + (j >> 3), y = j & 7) of the tile: 8 voxels x 128 B
+            unsigned rd = img + (lane >> 3) * G::EPI_PITCH + (lane & 7) * 16;
+            asm volatile("" : "+v"(rd));
+            const unsigned lane_off = (unsigned)(lane >> 3) * p.Cout * 2 + (lane & 7) * 16;
+            half_t *obase = p.out + ((((size_t)cur.n * p.Do + cur.oz0 + 2 * wave) * p.Ho + cur.oy0) * p.Wo + cur.ox0) * p.Cout + co_blk;
+            static_for<0, 16>([&](auto j_c) {
+                constexpr int j = decltype(j_c)::value;
+                const f32x4 v = *(const __attribute__((address_space(3))) f32x4 *)(rd + j * 8 * G::EPI_PITCH);
+                const char *row = (const char *)(obase + ((size_t)(j >> 3) * p.Ho + (j & 7)) * p.Wo * p.Cout);
+                const unsigned lo = lane_off;
+                asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(lo), "v"(v), "s"(row) : "memory");
+            });
+            if constexpr (STATS) {
+                __syncthreads();
+                if (tid < NF * 32 * 2) {
+                    const int c = tid >> 1, k = tid & 1;
+                    double tot = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
+                    atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co_blk + c) * 2 + k, quantise_partial(tot, k, (long)p.Do * p.Ho * p.Wo));  // exact, hence order-independent (common.h)
+                }
+                __syncthreads();  // (red is written again by the next tile)
+            }
+        }
         cur = nxt_tile;
+        H16_T(t_e1);
+        H16_ACC(4, t_e0, t_e1);
+#ifdef MI355_H16_STAMPS
+        if (stamp_on) h16_acc[7] += 1;
+#endif
     }
+#ifdef MI355_H16_STAMPS
+    if (stamp_on) {
+        const unsigned long long t_k1 = __builtin_readcyclecounter();
+        h16_acc[5] = t_k1 - t_k0;
+        for (int k = 0; k < 10; ++k) h16_stamps[(blockIdx.x & 1023) * 16 + k] += h16_acc[k];
+    }
+#endif
+#undef H16_WLOAD
+#undef H16_WWAIT
 }
 
 // ------------------------------------------------------------------ host side
@@ -906,7 +1134,6 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
     a.nchunks = w.cin_pad / 16;
     a.act = c.act; a.slope = c.slope;
     a.total_tiles = 0;
-    a.zeros = nullptr;
     a.ksplit = 1; a.partial = nullptr; a.out_elems = 0;
     a.in_scale = c.in_scale; a.in_shift = c.in_shift; a.in_act = c.in_act;
     MI355_REQUIRE(!c.in_scale || (c.in_shift && conv3d_f16_fuses_input_norm(w, c)), "input normalisation can only be fused into the pipelined stride-1 kernel");
@@ -948,6 +1175,34 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
             }
         }
     }
+    if (st == 1 && use_pipe_h() && w.nf == 2 && !c.head_out && !c.in_scale) {
+        // LDS-DMA kernel: 8 x 8 x 8 tiles x 64 couts, one workgroup per CU (MI355_F16_DMA=0: the register-staged kernel)
+        static int dmak = -1;
+        if (dmak < 0) { const char *e = getenv("MI355_F16_DMA"); dmak = (e && e[0] == '0') ? 0 : 1; }
+        ConvArgsH b = a;
+        b.lx = b.ly = b.lz = 3;
+        b.tiles_x = ceil_div(b.Wo, 8); b.tiles_y = ceil_div(b.Ho, 8); b.tiles_z = ceil_div(b.Do, 8);
+        b.IX = b.IY = b.IZ = 10;
+        b.div_tiles_per_n = make_fastdiv(b.tiles_x * b.tiles_y * b.tiles_z);
+        const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
+        const long cmax = c.C0 > c.C1 ? c.C0 : c.C1;
+        if (dmak && tiles * gy >= 512 && tiles < (1l << 30) && b.Do % 8 == 0 && b.Ho % 8 == 0 && b.Wo % 8 == 0 &&
+            (long)10 * c.Hi * c.Wi < (1l << 24) && (long)10 * c.Hi * c.Wi * cmax * 2 < (1l << 32)) {
+            void *zeros = nullptr;  // the zero page out-of-volume DMA pieces read
+            MI355_TRY(device_scratch(SCR_ZEROS, 256, &zeros, true));
+            b.zeros = zeros;
+            b.total_tiles = (int)tiles;
+            b.order = make_tile_order(b.tiles_x, b.tiles_y, b.tiles_z);
+            int gx = 256 / gy;
+            gx = gx < 8 ? 8 : (gx / 8) * 8;
+            const int need = (int)((tiles + 7) / 8) * 8;
+            if (gx > need) gx = need;
+            static size_t attr_dma[2] = {48 * 1024, 48 * 1024};
+            if (kernel_name) *kernel_name = c.stats ? "conv3_f16_dma_kernel<true>" : "conv3_f16_dma_kernel<false>";
+            if (c.stats) return launch_h(conv3_f16_dma_kernel<true>, b, dim3(gx, gy), DmaGeomH::LDS_BYTES, s, &attr_dma[0]);
+            return launch_h(conv3_f16_dma_kernel<false>, b, dim3(gx, gy), DmaGeomH::LDS_BYTES, s, &attr_dma[1]);
+        }
+    }
     if (st == 1 && use_pipe_h()) {
         int MF = 4;
         fill_geometry_h(a, 1, 128 * MF);
@@ -987,44 +1242,24 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1>, a, grid, lds_bytes, s, &attr[1]);
         return launch_h(conv3_f16_mfma_pipe_kernel<2, 2>, a, grid, lds_bytes, s, &attr[2]);
     }
-    if (st == 2 && w.nf == 2 && !c.head_out) {
-        static int s2dma = -1;
-        if (s2dma < 0) { const char *e = getenv("MI355_S2_DMA"); s2dma = (e && e[0] == '0') ? 0 : 1; }
+    if (st == 2 && w.nf == 2 && !c.head_out && use_pipe_h()) {
+        // round 2: the pipelined kernel with STRIDE = 2 (register-staged, two lanes per voxel) for the large stride-2 launches
+        static int s2pipe = -1;  // MI355_S2_DMA=0: the one-tile-per-workgroup kernel instead (the switch of the f32 stride-2 kernel)
+        if (s2pipe < 0) { const char *e = getenv("MI355_S2_DMA"); s2pipe = (e && e[0] == '0') ? 0 : 1; }
         ConvArgsH b = a;
-        const int txl = b.Wo >= 24 ? 5 : 4;  // 2 x 2 x 32 tiles, or 2 x 4 x 16 on narrow volumes
-        const int TX = 1 << txl, TY = 64 >> txl;
-        b.lz = 1; b.ly = 6 - txl; b.lx = txl;
-        b.tiles_x = ceil_div(b.Wo, TX); b.tiles_y = ceil_div(b.Ho, TY); b.tiles_z = ceil_div(b.Do, 2);
-        b.IX = 2 * TX + 1; b.IY = 2 * TY + 1; b.IZ = 5;
-        b.div_tiles_per_n = make_fastdiv(b.tiles_x * b.tiles_y * b.tiles_z);
-        b.div_tiles_x = make_fastdiv(b.tiles_x);
-        b.div_tiles_y = make_fastdiv(b.tiles_y);
-        b.div_IX = make_fastdiv(b.IX);
-        b.div_IY = make_fastdiv(b.IY);
+        fill_geometry_h(b, 2, 128);
         const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
-        const int gy2 = w.cout / 64;
-        if (s2dma && tiles * gy2 >= 768 && tiles < (1l << 30) && b.Wo >= 12 && b.Ho >= 3 &&
-            (long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) < (1l << 31)) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f16_s2dma_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2GeomH<5>::LDS_BYTES));
-                MI355_HIP(hipFuncSetAttribute((const void *)conv3_f16_s2dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2GeomH<4>::LDS_BYTES));
-                attr_set = true;
-            }
-            void *zeros = nullptr;
-            MI355_TRY(device_scratch(SCR_ZEROS, 256, &zeros, true));
-            b.zeros = zeros;
+        const size_t lds_bytes = (size_t)4 * b.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float);
+        if (s2pipe && tiles * gy >= 768 && tiles < (1l << 30) && b.IX * b.IY * b.IZ <= 13 * 128 && lds_bytes <= 160 * 1024 &&
+            (long)b.IZ * c.Hi * c.Wi < (1l << 24) && !c.in_scale) {
             b.total_tiles = (int)tiles;
-            b.order = make_tile_order(b.tiles_x, b.tiles_y, b.tiles_z);
-            int gx = 256 / gy2;
+            int gx = 256 / gy;   // one workgroup per CU: the double-buffered brick takes about 100 KB of LDS
             gx = gx < 8 ? 8 : (gx / 8) * 8;
             const int need = (int)((tiles + 7) / 8) * 8;
             if (gx > need) gx = need;
-            if (kernel_name) *kernel_name = txl == 5 ? "conv3_f16_s2dma_kernel<5>" : "conv3_f16_s2dma_kernel<4>";
-            if (txl == 5) hipLaunchKernelGGL(conv3_f16_s2dma_kernel<5>, dim3(gx, gy2), dim3(256), S2GeomH<5>::LDS_BYTES, s, b);
-            else hipLaunchKernelGGL(conv3_f16_s2dma_kernel<4>, dim3(gx, gy2), dim3(256), S2GeomH<4>::LDS_BYTES, s, b);
-            MI355_HIP(hipGetLastError());
-            return MI355_OK;
+            if (kernel_name) *kernel_name = "conv3_f16_mfma_pipe_kernel<1, 2, false, false, 2>";
+            static size_t attr_s2 = 48 * 1024;
+            return launch_h(conv3_f16_mfma_pipe_kernel<1, 2, false, false, 2>, b, dim3(gx, gy), lds_bytes, s, &attr_s2);
         }
     }
     const int MF = (st == 1) ? 2 : 1;

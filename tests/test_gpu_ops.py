@@ -162,12 +162,15 @@ F16_CONV_CASES = [
     (1, 16, 16, 32, 4, 64, 1, 0),
     (3, 9, 7, 131, 48, 96, 2, 1),    # stride 2: odd input dims, ragged x tiles, 3 chunks of 16, 3 cout blocks
     (1, 64, 64, 64, 32, 64, 2, 1),   # stride 2 at a network-like size
-    (2, 64, 64, 128, 32, 64, 2, 1),  # stride 2, >= 768 tiles: the persistent LDS-DMA stride-2 kernel
+    (2, 64, 64, 128, 32, 64, 2, 1),  # stride 2, >= 768 tiles: the pipelined kernel's STRIDE = 2 instantiation
     (3, 50, 62, 90, 16, 128, 2, 0),  # the same kernel: ragged in z, y, x (odd input dims), two cout blocks, batch
     (8, 32, 30, 32, 128, 256, 2, 1), # the same kernel on a narrow volume (Wo = 16): 2 x 4 x 16 tiles, 8 chunks
     (8, 8, 8, 8, 320, 320, 1, 1),    # deep level: split-K over the 20 channel chunks + finishing pass
     (8, 16, 16, 16, 256, 320, 2, 0), # deep stride-2 level: split-K, no activation
     (2, 4, 4, 4, 320, 320, 1, 1),    # bottleneck-sized launch
+    (8, 32, 32, 32, 64, 64, 1, 1),   # Cout % 64 == 0, volume a whole number of 8^3 tiles, >= 512 tiles: the LDS-DMA kernel
+    (2, 32, 64, 64, 48, 128, 1, 0),  # the same kernel: 3 chunks, two cout blocks, no activation
+    (3, 24, 40, 72, 16, 64, 1, 1),   # the same kernel: one chunk, odd tile counts (3 x 5 x 9), batch 3
 ]
 
 
