@@ -66,37 +66,63 @@ __device__ __forceinline__ void stem_tile(const StemArgs &p, int &n, int &oz0, i
 }
 
 // Epilogue for the fixed 4x4x32 tile: lane = voxel (x = lane&31, y = fragment, z = wave), 16 couts per lane.
+// Round 2: the 32 voxels x 32 couts of a fragment are one x-row of the output - 4 KiB (fp32) / 2 KiB (fp16) that are
+// contiguous in memory when Cout = 32 - but a lane holds 4 x 4 couts of ONE voxel, and stored from the registers every
+// instruction wrote 16 (8) bytes to each of 32 lines.  Each wave now transposes the fragment through a private LDS image
+// (row = voxel, padded pitch) and stores 16 B per lane over whole 128-B lines: this kernel is bound by its output stream
+// (2.1 GB per launch in fp32), which was reaching the HBM at a third of its rate.
+template <typename T>
+struct StemEpi {
+    static constexpr int ROW = 32 * sizeof(T);       // bytes of one voxel's 32 couts
+    static constexpr int PITCH = ROW + 16;           // padded: consecutive voxels start 4 banks apart
+    static constexpr int WAVE_BYTES = 32 * PITCH;
+    static constexpr int UNITS = ROW / 16;           // 16-B pieces per voxel: 8 (fp32) / 4 (fp16)
+    static constexpr int STORES = 32 * UNITS / 64;   // store instructions per fragment: 4 / 2
+};
+
 template <typename T>
 __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &p, int n, int oz0, int oy0, int ox0,
-                                              int co_blk, float *red) {
+                                              int co_blk, float *red, char *img_all) {
+    typedef StemEpi<T> E;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     float s1[16], s2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
     const float slope = p.act == ACT_LRELU ? p.slope : 1.0f;
+    char *img = img_all + wave * E::WAVE_BYTES;
+    f32x4 bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = *(const f32x4 *)(p.bias + co_blk + 8 * g + 4 * half);
+    const int oz = oz0 + wave;
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf) {
-        const int oz = oz0 + wave, oy = oy0 + mf, ox = ox0 + l31;
-        const bool ok = (oz < p.D) && (oy < p.H) && (ox < p.W);
-        T *orow = (T *)p.out + ((((size_t)n * p.D + oz) * p.H + oy) * p.W + ox) * p.Cout + co_blk + 4 * half;
+        const int oy = oy0 + mf;
+        const bool ok = (oz < p.D) && (oy < p.H) && (ox0 + l31 < p.W);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 bias = *(const f32x4 *)(p.bias + co_blk + 8 * g + 4 * half);
             f32x4 val;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float x = acc[mf][4 * g + k] + bias[k];
+                float x = acc[mf][4 * g + k] + bias[g][k];
                 x = fmaxf(x, x * slope);
                 val[k] = x;
                 if (ok && p.stats) { s1[4 * g + k] += x; s2[4 * g + k] += x * x; }
             }
-            if (ok) {
-                if (sizeof(T) == 4) *(f32x4 *)(orow + 8 * g) = val;
-                else {
-                    f16x4 hv = {(_Float16)val[0], (_Float16)val[1], (_Float16)val[2], (_Float16)val[3]};
-                    *(f16x4 *)(orow + 8 * g) = hv;
-                }
+            char *dst = img + l31 * E::PITCH + (8 * g + 4 * half) * (int)sizeof(T);
+            if (sizeof(T) == 4) *(f32x4 *)dst = val;
+            else {
+                f16x4 hv = {(_Float16)val[0], (_Float16)val[1], (_Float16)val[2], (_Float16)val[3]};
+                *(f16x4 *)dst = hv;
             }
+        }
+        // (same wave wrote the image: the LDS executes a wave's accesses in order, the compiler inserts the wait)
+        char *orow = (char *)p.out + ((((size_t)n * p.D + oz) * p.H + oy) * p.W + ox0) * p.Cout * sizeof(T) + co_blk * sizeof(T);
+        const bool row_ok = (oz < p.D) && (oy < p.H);
+#pragma unroll
+        for (int j = 0; j < E::STORES; ++j) {
+            const int q = j * 64 + lane, vox = q / E::UNITS, unit = q % E::UNITS;
+            const f32x4 v = *(const f32x4 *)(img + vox * E::PITCH + unit * 16);
+            if (row_ok && ox0 + vox < p.W) *(f32x4 *)(orow + (size_t)vox * p.Cout * sizeof(T) + unit * 16) = v;
         }
     }
     if (p.stats) {
@@ -163,13 +189,13 @@ __global__ __launch_bounds__(256, 3) void conv3_stem_f32_kernel(StemArgs p) {
                     for (int mf = 0; mf < 4; ++mf)
                         acc[mf] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[(dz * 3 + dy) * 3 + dx][j], a[mf][dx][j], acc[mf], 0, 0, 0);
         }
-    stem_epilogue<float>(acc, p, n, oz0, oy0, ox0, co_blk, (float *)lds);
+    stem_epilogue<float>(acc, p, n, oz0, oy0, ox0, co_blk, (float *)lds, lds + S_BRICK * 16);
 }
 
 // ---------------------------------------------------------------- fp16
 // weights: [cout block][(dz,dy) 9][lane 64][8 halfs]: lane (cout, h): h = 0 -> W[c0..3][dx0], W[c0..3][dx1];
 // h = 1 -> W[c0..3][dx2], 0, 0, 0, 0
-__global__ __launch_bounds__(256, 3) void conv3_stem_f16_kernel(StemArgs p) {
+__global__ __launch_bounds__(256, 4) void conv3_stem_f16_kernel(StemArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     int n, oz0, oy0, ox0;
@@ -200,7 +226,7 @@ __global__ __launch_bounds__(256, 3) void conv3_stem_f16_kernel(StemArgs p) {
                 acc[mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[dz * 3 + dy], a, acc[mf], 0, 0, 0);
             }
         }
-    stem_epilogue<_Float16>(acc, p, n, oz0, oy0, ox0, co_blk, (float *)lds);
+    stem_epilogue<_Float16>(acc, p, n, oz0, oy0, ox0, co_blk, (float *)lds, lds + S_BRICK * 8);
 }
 
 // ---------------------------------------------------------------- host
@@ -263,10 +289,9 @@ int conv3d_stem(const StemWeights &w, const void *in, int N, int D, int H, int W
     a.act = act; a.slope = slope;
     dim3 grid((unsigned)tiles, w.cout / 32);
     if (w.dtype == MI355_F16) {
-        const size_t lds = (size_t)S_BRICK * 8 < 2048 ? 2048 : (size_t)S_BRICK * 8;
-        hipLaunchKernelGGL(conv3_stem_f16_kernel, grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL(conv3_stem_f16_kernel, grid, dim3(256), (size_t)S_BRICK * 8 + 4 * StemEpi<_Float16>::WAVE_BYTES, s, a);
     } else {
-        hipLaunchKernelGGL(conv3_stem_f32_kernel, grid, dim3(256), (size_t)S_BRICK * 16, s, a);
+        hipLaunchKernelGGL(conv3_stem_f32_kernel, grid, dim3(256), (size_t)S_BRICK * 16 + 4 * StemEpi<float>::WAVE_BYTES, s, a);
     }
     MI355_HIP(hipGetLastError());
     return MI355_OK;
