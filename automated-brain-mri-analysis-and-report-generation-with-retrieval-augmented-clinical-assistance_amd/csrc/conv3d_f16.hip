@@ -673,16 +673,14 @@ __device__ unsigned long long h16_stamps[1024 * 16];
 #define H16_T(v)
 #define H16_ACC(k, a, b)
 #endif
+template <int EVERY_>
 struct DmaGeomH {
     static constexpr int IX = 10, IY = 10, IZ = 10, BV = IX * IY * IZ;
     static constexpr int PLANE_SLOTS = 1024, PLANE_BYTES = PLANE_SLOTS * 16, BUF_BYTES = 2 * PLANE_BYTES;
     static constexpr int D = 9;    // weight ring depth in taps (divides 27: the ring phase is the same in every chunk)
     static constexpr int KD = 8;   // DMAs per wave and chunk: range wave + 4 (k & 3) of plane k >> 2
-#ifndef MI355_H16_DMA_EVERY
-#define MI355_H16_DMA_EVERY 3
-#endif
-    static constexpr int EVERY = MI355_H16_DMA_EVERY;  // DMA k goes out in tap EVERY * k: four waves issuing 64-line DMAs in the same
-                                                       // tap ask the L1 for more lines than a tap has cycles (stamps: +1.3-2.2k per chunk)
+    static constexpr int EVERY = EVERY_;  // DMA k goes out in tap EVERY * k: four waves issuing 64-line DMAs in the same tap ask the
+                                          // L1 for more lines than a tap has cycles (stamps: +1.3-2.2k cycles per chunk at EVERY = 1)
     static constexpr bool dma_tap(int t) { return t % EVERY == 0 && t / EVERY < KD; }
     // loads issued after the weight loads of tap t (which went out at the end of tap t - D): two per tap of taps t-8 .. t-1
     // and the DMAs among those taps (taps < 0 are the previous chunk's)
@@ -697,13 +695,25 @@ struct DmaGeomH {
     // 8-B writes of 32 consecutive voxels spread over all banks) and stores whole 128-B lines
     static constexpr int EPI_PITCH = 144, EPI_WAVE_BYTES = 128 * EPI_PITCH;
     static constexpr int RED_OFF = 2 * BUF_BYTES, BIAS_OFF = RED_OFF + 4 * 64 * 2 * 4, EPI_OFF = BIAS_OFF + 64 * 4;
-    static constexpr size_t LDS_BYTES = (size_t)EPI_OFF + 4 * EPI_WAVE_BYTES;
+    // INAFF: a 1-KiB junk area (the write target of out-of-volume pieces) and the fp16 scale / shift tables [N][C0]
+    static constexpr int JUNK_OFF = EPI_OFF + 4 * EPI_WAVE_BYTES, TAB_OFF = JUNK_OFF + 1024;
+    static constexpr size_t LDS_BYTES = (size_t)JUNK_OFF;
+    static constexpr int TAB_MAX_BYTES = 160 * 1024 - TAB_OFF;
+    // INAFF: piece k (DMA in tap EVERY k) has landed once the weights of tap EVERY k + 10 have been waited for (they were
+    // issued after it); it is read back in that tap and normalised + written in the next one
+    static constexpr int aff_read_tap(int k) { return EVERY * k + 10; }
 };
 
-template <bool STATS>
+// INAFF (round 2): the producer's Instance/GroupNorm + LeakyReLU applied to the brick IN LDS.  The DMA cannot touch the data
+// in flight, so each lane normalises the eight pieces it fetched itself, in place, ten taps after their DMA (the weight
+// waits guarantee they have landed): ds_read_b128, 12 packed fp16 ops, ds_write_b128, dealt out over the taps.  Out-of-volume
+// pieces (zeros from the zero page; padding follows the norm) are written to a junk area instead.  Same arithmetic as the
+// pipelined kernel's INAFF path: scale and shift as fp16, one fused multiply-add, max(y, slope y).
+template <bool STATS, bool INAFF = false>
 __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    typedef DmaGeomH G;
+    typedef DmaGeomH<INAFF ? 2 : 3> G;
+    static_assert(!INAFF || G::aff_read_tap(G::KD - 1) + 1 <= 26, "the last piece must be normalised within its chunk");
     constexpr int MF = 4, NF = 2;
     constexpr int IX = G::IX, IY = G::IY;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -711,6 +721,11 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     float *red = (float *)(lds_raw + G::RED_OFF);
     float *bias_lds = (float *)(lds_raw + G::BIAS_OFF);
     if (tid < 64) bias_lds[tid] = p.bias[(int)blockIdx.y * NF * 32 + tid];  // (published by the prologue's barrier)
+    const int tab_n = p.N * p.C0;  // INAFF: fp16 scale [N][C0], then shift [N][C0]
+    if constexpr (INAFF) {
+        half_t *tab = (half_t *)(lds_raw + G::TAB_OFF);
+        for (int i = tid; i < tab_n; i += 256) { tab[i] = (half_t)p.in_scale[i]; tab[tab_n + i] = (half_t)p.in_shift[i]; }
+    }
 
     // this workgroup's tile sequence: XCD group x owns the contiguous range [lo, hi); its workgroups stride through it
     const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
@@ -771,6 +786,33 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                                          16, (k >> 2) * 16, 0);
     };
 
+    // INAFF: this lane's piece k of a brick buffer, read back / normalised and written in place (see above the kernel)
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    const half_t slope_in = (half_t)(p.in_act == ACT_LRELU ? p.slope : 1.0f);
+    auto aff_read = [&](char *buf, auto k_c) {
+        constexpr int k = decltype(k_c)::value;
+        const unsigned a = (unsigned)(size_t)(lds_char_t *)buf + wave * 1024 + lane * 16;
+        return *(const __attribute__((address_space(3))) f32x4 *)(a + (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024);
+    };
+    auto aff_apply = [&](const TileCoord &tc, int faces, int ch, auto k_c, char *buf, f32x4 raw) {
+        constexpr int k = decltype(k_c)::value;
+        unsigned ta = (unsigned)(size_t)(lds_char_t *)(lds_raw + G::TAB_OFF) + (tc.n * p.C0 + ch * 16 + (k >> 2) * 8) * 2;
+        asm volatile("" : "+v"(ta));
+        const f16x8 sc = *(const __attribute__((address_space(3))) f16x8 *)ta;
+        const f16x8 sh = *(const __attribute__((address_space(3))) f16x8 *)(ta + tab_n * 2);
+        f16x8 y = __builtin_elementwise_fma(__builtin_bit_cast(f16x8, raw), sc, sh);
+        const f16x8 sl8 = {slope_in, slope_in, slope_in, slope_in, slope_in, slope_in, slope_in, slope_in};
+        y = __builtin_elementwise_max(y, y * sl8);
+        unsigned pk = dma_pk[k & 3];
+        asm volatile("" : "+v"(pk));
+        const bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
+        const unsigned slot = (unsigned)(size_t)(lds_char_t *)buf + wave * 1024 + lane * 16 + (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024;
+        const unsigned junk = (unsigned)(size_t)(lds_char_t *)(lds_raw + G::JUNK_OFF) + lane * 16;
+        unsigned dst = inside ? slot : junk;  // (padding follows the norm: out-of-volume pieces stay the zeros the DMA wrote)
+        asm volatile("" : "+v"(dst));
+        *(__attribute__((address_space(3))) f32x4 *)dst = __builtin_bit_cast(f32x4, y);
+    };
+
     // LDS byte offsets of this lane's voxel fragments in a brick buffer (tap (0,0,0)); fragment mf of wave w holds the
     // voxels v = (4 w + mf) * 32 + l31 of the tile: x = v & 7, y = (v >> 3) & 7, z = v >> 6
     int a_base[MF];
@@ -805,6 +847,10 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
         });
         // (the ring registers are operands of the wait: the compiler must not read or move them before it)
         static_for<0, G::D>([&](auto t_c) { auto &w = wq[decltype(t_c)::value]; H16_WWAIT(w, 0); });
+        if constexpr (INAFF) {
+            __syncthreads();  // the tables
+            static_for<0, G::KD>([&](auto k_c) { aff_apply(cur, f0, 0, k_c, lds_raw, aff_read(lds_raw, k_c)); });
+        }
         __syncthreads();
     }
 
@@ -865,6 +911,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
 #ifdef MI355_H16_STAMPS
             unsigned long long t_seg = t_c0;
 #endif
+            f32x4 aff_raw = {0.f, 0.f, 0.f, 0.f};
             static_for<0, 27>([&](auto tap_c) {
                 constexpr int tap = decltype(tap_c)::value;
                 constexpr int slot = tap % G::D;
@@ -880,6 +927,13 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                     acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[slot][nf], a[tap & 1][mf], acc[mf][nf], 0, 0, 0);
                     if constexpr (i == 1) {
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (INAFF) {  // (before this tap's LDS reads: the piece read a tap ago is complete, nothing is waited for)
+                            constexpr int ta = tap - 11, tr = tap - 10;
+                            if constexpr (ta >= 0 && ta % G::EVERY == 0 && ta / G::EVERY < G::KD)
+                                aff_apply(nxt, nfaces, nch_eff, std::integral_constant<int, ta / G::EVERY>{}, bufn, aff_raw);
+                            if constexpr (tr >= 0 && tr % G::EVERY == 0 && tr / G::EVERY < G::KD)
+                                aff_raw = aff_read(bufn, std::integral_constant<int, tr / G::EVERY>{});
+                        }
                         if constexpr (tap + 1 < 27) {
                             constexpr int nt = tap + 1;
                             constexpr int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
@@ -910,6 +964,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
             // publishes the brick (a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier)
             H16_T(t_c2);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::after_last_dma) : "memory");
+            if constexpr (INAFF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the in-place writes of the normalised pieces
             __builtin_amdgcn_s_barrier();
             buf ^= 1;
             H16_T(t_c3);
@@ -1105,8 +1160,9 @@ static bool use_pipe_h() {
     return v == 1;
 }
 
-// Whether conv3d_mfma_f16 would run this call on the pipelined stride-1 kernel, the one that can apply the producer's
-// normalisation while staging (register staging; the LDS-DMA and split-K kernels cannot).  Mirrors the dispatch below.
+// Whether conv3d_mfma_f16 would run this call on a kernel that can apply the producer's normalisation to its input: the
+// pipelined stride-1 kernel (while staging through registers) or the LDS-DMA kernel (in LDS); the split-K and stride-2
+// kernels cannot.  Mirrors the dispatch below.
 bool conv3d_f16_fuses_input_norm(const ConvWeightsH &w, const ConvCallH &c) {
     static int on = -1;
     if (on < 0) { const char *e = getenv("MI355_FUSE_NORM"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -1136,7 +1192,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
     a.total_tiles = 0;
     a.ksplit = 1; a.partial = nullptr; a.out_elems = 0;
     a.in_scale = c.in_scale; a.in_shift = c.in_shift; a.in_act = c.in_act;
-    MI355_REQUIRE(!c.in_scale || (c.in_shift && conv3d_f16_fuses_input_norm(w, c)), "input normalisation can only be fused into the pipelined stride-1 kernel");
+    MI355_REQUIRE(!c.in_scale || (c.in_shift && conv3d_f16_fuses_input_norm(w, c)), "input normalisation can only be fused into the stride-1 kernels");
     const int gy = w.cout / (32 * w.nf);
     static size_t attr[8] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
     {
@@ -1175,7 +1231,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
             }
         }
     }
-    if (st == 1 && use_pipe_h() && w.nf == 2 && !c.head_out && !c.in_scale) {
+    if (st == 1 && use_pipe_h() && w.nf == 2 && !c.head_out) {
         // LDS-DMA kernel: 8 x 8 x 8 tiles x 64 couts, one workgroup per CU (MI355_F16_DMA=0: the register-staged kernel)
         static int dmak = -1;
         if (dmak < 0) { const char *e = getenv("MI355_F16_DMA"); dmak = (e && e[0] == '0') ? 0 : 1; }
@@ -1186,8 +1242,11 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         b.div_tiles_per_n = make_fastdiv(b.tiles_x * b.tiles_y * b.tiles_z);
         const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
         const long cmax = c.C0 > c.C1 ? c.C0 : c.C1;
+        typedef DmaGeomH<2> GA;
+        const size_t tab_bytes = c.in_scale ? (size_t)c.N * c.C0 * 4 : 0;  // fused input norm: fp16 scale + shift tables in LDS
         if (dmak && tiles * gy >= 512 && tiles < (1l << 30) && b.Do % 8 == 0 && b.Ho % 8 == 0 && b.Wo % 8 == 0 &&
-            (long)10 * c.Hi * c.Wi < (1l << 24) && (long)10 * c.Hi * c.Wi * cmax * 2 < (1l << 32)) {
+            (long)10 * c.Hi * c.Wi < (1l << 24) && (long)10 * c.Hi * c.Wi * cmax * 2 < (1l << 32) &&
+            (!c.in_scale || (c.C1 == 0 && tab_bytes <= (size_t)GA::TAB_MAX_BYTES))) {
             void *zeros = nullptr;  // the zero page out-of-volume DMA pieces read
             MI355_TRY(device_scratch(SCR_ZEROS, 256, &zeros, true));
             b.zeros = zeros;
@@ -1197,10 +1256,16 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
             gx = gx < 8 ? 8 : (gx / 8) * 8;
             const int need = (int)((tiles + 7) / 8) * 8;
             if (gx > need) gx = need;
-            static size_t attr_dma[2] = {48 * 1024, 48 * 1024};
+            static size_t attr_dma[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+            if (c.in_scale) {
+                const size_t lds_aff = (size_t)GA::TAB_OFF + tab_bytes;
+                if (kernel_name) *kernel_name = c.stats ? "conv3_f16_dma_kernel<true, true>" : "conv3_f16_dma_kernel<false, true>";
+                if (c.stats) return launch_h(conv3_f16_dma_kernel<true, true>, b, dim3(gx, gy), lds_aff, s, &attr_dma[2]);
+                return launch_h(conv3_f16_dma_kernel<false, true>, b, dim3(gx, gy), lds_aff, s, &attr_dma[3]);
+            }
             if (kernel_name) *kernel_name = c.stats ? "conv3_f16_dma_kernel<true>" : "conv3_f16_dma_kernel<false>";
-            if (c.stats) return launch_h(conv3_f16_dma_kernel<true>, b, dim3(gx, gy), DmaGeomH::LDS_BYTES, s, &attr_dma[0]);
-            return launch_h(conv3_f16_dma_kernel<false>, b, dim3(gx, gy), DmaGeomH::LDS_BYTES, s, &attr_dma[1]);
+            if (c.stats) return launch_h(conv3_f16_dma_kernel<true>, b, dim3(gx, gy), DmaGeomH<3>::LDS_BYTES, s, &attr_dma[0]);
+            return launch_h(conv3_f16_dma_kernel<false>, b, dim3(gx, gy), DmaGeomH<3>::LDS_BYTES, s, &attr_dma[1]);
         }
     }
     if (st == 1 && use_pipe_h()) {
