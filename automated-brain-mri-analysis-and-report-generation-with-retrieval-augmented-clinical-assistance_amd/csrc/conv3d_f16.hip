@@ -789,26 +789,31 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     // INAFF: this lane's piece k of a brick buffer, read back / normalised and written in place (see above the kernel)
     typedef __attribute__((address_space(3))) char lds_char_t;
     const half_t slope_in = (half_t)(p.in_act == ACT_LRELU ? p.slope : 1.0f);
-    auto aff_read = [&](char *buf, auto k_c) {
-        constexpr int k = decltype(k_c)::value;
-        const unsigned a = (unsigned)(size_t)(lds_char_t *)buf + wave * 1024 + lane * 16;
-        return *(const __attribute__((address_space(3))) f32x4 *)(a + (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024);
+    // (per chunk: `pb` = this lane's slot 0 of the buffer, `ta` / `tb` = the chunk's rows of the scale / shift tables - the
+    //  per-piece parts are instruction immediates; recomputed per piece these addresses were half of the pass's VALU work)
+    unsigned aff_junk = (unsigned)(size_t)(lds_char_t *)(lds_raw + G::JUNK_OFF) + lane * 16;
+    auto aff_bases = [&](char *buf, const TileCoord &tc, int ch, unsigned &pb, unsigned &ta, unsigned &tb) {
+        pb = (unsigned)(size_t)(lds_char_t *)buf + wave * 1024 + lane * 16;
+        ta = (unsigned)(size_t)(lds_char_t *)(lds_raw + G::TAB_OFF) + (tc.n * p.C0 + ch * 16) * 2;
+        tb = ta + tab_n * 2;
+        asm volatile("" : "+v"(pb), "+v"(ta), "+v"(tb));
     };
-    auto aff_apply = [&](const TileCoord &tc, int faces, int ch, auto k_c, char *buf, f32x4 raw) {
+    auto aff_read = [&](unsigned pb, auto k_c) {
         constexpr int k = decltype(k_c)::value;
-        unsigned ta = (unsigned)(size_t)(lds_char_t *)(lds_raw + G::TAB_OFF) + (tc.n * p.C0 + ch * 16 + (k >> 2) * 8) * 2;
-        asm volatile("" : "+v"(ta));
-        const f16x8 sc = *(const __attribute__((address_space(3))) f16x8 *)ta;
-        const f16x8 sh = *(const __attribute__((address_space(3))) f16x8 *)(ta + tab_n * 2);
+        return *(const __attribute__((address_space(3))) f32x4 *)(pb + (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024);
+    };
+    auto aff_apply = [&](int faces, auto k_c, unsigned pb, unsigned ta, unsigned tb, f32x4 raw) {
+        constexpr int k = decltype(k_c)::value;
+        const f16x8 sc = *(const __attribute__((address_space(3))) f16x8 *)(ta + (k >> 2) * 16);
+        const f16x8 sh = *(const __attribute__((address_space(3))) f16x8 *)(tb + (k >> 2) * 16);
         f16x8 y = __builtin_elementwise_fma(__builtin_bit_cast(f16x8, raw), sc, sh);
         const f16x8 sl8 = {slope_in, slope_in, slope_in, slope_in, slope_in, slope_in, slope_in, slope_in};
         y = __builtin_elementwise_max(y, y * sl8);
         unsigned pk = dma_pk[k & 3];
         asm volatile("" : "+v"(pk));
         const bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
-        const unsigned slot = (unsigned)(size_t)(lds_char_t *)buf + wave * 1024 + lane * 16 + (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024;
-        const unsigned junk = (unsigned)(size_t)(lds_char_t *)(lds_raw + G::JUNK_OFF) + lane * 16;
-        unsigned dst = inside ? slot : junk;  // (padding follows the norm: out-of-volume pieces stay the zeros the DMA wrote)
+        // (padding follows the norm: out-of-volume pieces stay the zeros the DMA wrote; their result goes to the junk area)
+        unsigned dst = inside ? pb + ((k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024) : aff_junk;
         asm volatile("" : "+v"(dst));
         *(__attribute__((address_space(3))) f32x4 *)dst = __builtin_bit_cast(f32x4, y);
     };
@@ -849,7 +854,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
         static_for<0, G::D>([&](auto t_c) { auto &w = wq[decltype(t_c)::value]; H16_WWAIT(w, 0); });
         if constexpr (INAFF) {
             __syncthreads();  // the tables
-            static_for<0, G::KD>([&](auto k_c) { aff_apply(cur, f0, 0, k_c, lds_raw, aff_read(lds_raw, k_c)); });
+            unsigned pb, ta, tb;
+            aff_bases(lds_raw, cur, 0, pb, ta, tb);
+            static_for<0, G::KD>([&](auto k_c) { aff_apply(f0, k_c, pb, ta, tb, aff_read(pb, k_c)); });
         }
         __syncthreads();
     }
@@ -912,6 +919,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
             unsigned long long t_seg = t_c0;
 #endif
             f32x4 aff_raw = {0.f, 0.f, 0.f, 0.f};
+            unsigned aff_pb = 0, aff_ta = 0, aff_tb = 0;
+            if constexpr (INAFF) aff_bases(bufn, nxt, nch_eff, aff_pb, aff_ta, aff_tb);
             static_for<0, 27>([&](auto tap_c) {
                 constexpr int tap = decltype(tap_c)::value;
                 constexpr int slot = tap % G::D;
@@ -930,9 +939,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                         if constexpr (INAFF) {  // (before this tap's LDS reads: the piece read a tap ago is complete, nothing is waited for)
                             constexpr int ta = tap - 11, tr = tap - 10;
                             if constexpr (ta >= 0 && ta % G::EVERY == 0 && ta / G::EVERY < G::KD)
-                                aff_apply(nxt, nfaces, nch_eff, std::integral_constant<int, ta / G::EVERY>{}, bufn, aff_raw);
+                                aff_apply(nfaces, std::integral_constant<int, ta / G::EVERY>{}, aff_pb, aff_ta, aff_tb, aff_raw);
                             if constexpr (tr >= 0 && tr % G::EVERY == 0 && tr / G::EVERY < G::KD)
-                                aff_raw = aff_read(bufn, std::integral_constant<int, tr / G::EVERY>{});
+                                aff_raw = aff_read(aff_pb, std::integral_constant<int, tr / G::EVERY>{});
                         }
                         if constexpr (tap + 1 < 27) {
                             constexpr int nt = tap + 1;
@@ -1263,7 +1272,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
                 if (c.stats) return launch_h(conv3_f16_dma_kernel<true, true>, b, dim3(gx, gy), lds_aff, s, &attr_dma[2]);
                 return launch_h(conv3_f16_dma_kernel<false, true>, b, dim3(gx, gy), lds_aff, s, &attr_dma[3]);
             }
-            if (kernel_name) *kernel_name = c.stats ? "conv3_f16_dma_kernel<true>" : "conv3_f16_dma_kernel<false>";
+            if (kernel_name) *kernel_name = c.stats ? "conv3_f16_dma_kernel<true, false>" : "conv3_f16_dma_kernel<false, false>";
             if (c.stats) return launch_h(conv3_f16_dma_kernel<true>, b, dim3(gx, gy), DmaGeomH<3>::LDS_BYTES, s, &attr_dma[0]);
             return launch_h(conv3_f16_dma_kernel<false>, b, dim3(gx, gy), DmaGeomH<3>::LDS_BYTES, s, &attr_dma[1]);
         }
@@ -1288,17 +1297,17 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         const int need = (int)((tiles + 7) / 8) * 8;
         if (gx > need) gx = need;
         dim3 grid(gx, gy);
-        if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false>" : "conv3_f16_mfma_pipe_kernel<2, 2, false>");
+        if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false, false, 1>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false, false, 1>" : "conv3_f16_mfma_pipe_kernel<2, 2, false, false, 1>");
         if (c.head_out) {
             MI355_REQUIRE(w.nf == 1, "fused head: fp16 path supports Cout = 32 only");
-            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, true>" : "conv3_f16_mfma_pipe_kernel<2, 1, true>";
+            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, true, false, 1>" : "conv3_f16_mfma_pipe_kernel<2, 1, true, false, 1>";
             static size_t attr_head[2] = {48 * 1024, 48 * 1024};  // one slot per kernel: the attribute is per function
             if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, true>, a, grid, lds_bytes, s, &attr_head[0]);
             return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, true>, a, grid, lds_bytes, s, &attr_head[1]);
         }
         if (c.in_scale) {  // the producer's normalisation + activation applied while the brick is staged
             static size_t attr_aff[3] = {48 * 1024, 48 * 1024, 48 * 1024};
-            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false, true>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false, true>" : "conv3_f16_mfma_pipe_kernel<2, 2, false, true>");
+            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false, true, 1>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false, true, 1>" : "conv3_f16_mfma_pipe_kernel<2, 2, false, true, 1>");
             if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, false, true>, a, grid, lds_bytes, s, &attr_aff[0]);
             if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, false, true>, a, grid, lds_bytes, s, &attr_aff[1]);
             return launch_h(conv3_f16_mfma_pipe_kernel<2, 2, false, true>, a, grid, lds_bytes, s, &attr_aff[2]);

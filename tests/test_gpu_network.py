@@ -226,8 +226,11 @@ np.savez(sys.argv[1], y=y, names=np.array(names))
             assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
             outs[flag] = np.load(path)
     fused, plain = outs["1"], outs["0"]
-    assert any("false, true>" in n for n in fused["names"]), list(fused["names"])         # the INAFF kernels ran ...
-    assert not any("false, true>" in n for n in plain["names"])
+    def inaff(n):  # conv3_f16_mfma_pipe_kernel<MF, NF, HEAD, INAFF, STRIDE> / conv3_f16_dma_kernel<STATS, INAFF>
+        return ("pipe_kernel<" in n and n.split("<")[1].split(",")[3].strip() == "true") or ("dma_kernel<" in n and n.endswith(", true>"))
+    assert any(inaff(n) for n in fused["names"]), list(fused["names"])         # the INAFF kernels ran ...
+    assert any("dma_kernel<" in n and inaff(n) for n in fused["names"]), list(fused["names"])   # ... the in-LDS variant among them
+    assert not any(inaff(n) for n in plain["names"])
     spread = float(plain["y"].std())
     err = float(np.abs(fused["y"] - plain["y"]).max())
     print(f"PARITY fused-vs-separate norm (f16, B 64^3): {err / spread:.2e} x spread")
