@@ -957,7 +957,11 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                 __builtin_amdgcn_sched_barrier(0);
                 {
                     constexpr int k = tap + G::D;
+#ifdef MI355_H16_ABL_W   // (probe only: every tap reads the same 2 KB of weights - L1-resident, no L2 traffic; results wrong)
+                    const char *wb = wblk;
+#else
                     const char *wb = (k < 27) ? wch + k * (NF * 1024) : wnx + (k - 27) * (NF * 1024);
+#endif
                     const unsigned wl = wlane;
                     H16_WLOAD(wc[0], wb, 0);
                     H16_WLOAD(wc[1], wb, 1024);
