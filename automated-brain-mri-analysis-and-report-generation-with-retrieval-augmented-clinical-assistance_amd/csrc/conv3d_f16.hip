@@ -677,6 +677,16 @@ template <int EVERY_>
 struct DmaGeomH {
     static constexpr int IX = 10, IY = 10, IZ = 10, BV = IX * IY * IZ;
     static constexpr int PLANE_SLOTS = 1024, PLANE_BYTES = PLANE_SLOTS * 16, BUF_BYTES = 2 * PLANE_BYTES;
+#ifndef MI355_H16_INTERLEAVED
+#define MI355_H16_INTERLEAVED 1
+#endif
+    // Brick layout in LDS.  Interleaved [voxel][8-channel half][16 B] (round 2, second version): two adjacent lanes of a DMA
+    // fetch the 32 contiguous bytes of one voxel, so an instruction touches 32 lines instead of the 64 of the planar layout
+    // [half][voxel][16 B] - and the issue of the 64-line DMAs was this kernel's largest loss.  The price: the fragment reads
+    // (lane = voxel, stride 32 B) are 2-way bank conflicts, 32 instead of 16 cycles per wave-level ds_read_b128
+    // (tools/lds_probe.hip) - of an LDS that this kernel uses to a quarter (256 B/clk on gfx950).
+    static constexpr bool INTERLEAVED = MI355_H16_INTERLEAVED != 0;
+    static constexpr int VOX_BYTES = INTERLEAVED ? 32 : 16;
     static constexpr int D = 9;    // weight ring depth in taps (divides 27: the ring phase is the same in every chunk)
     static constexpr int KD = 8;   // DMAs per wave and chunk: range wave + 4 (k & 3) of plane k >> 2
     static constexpr int EVERY = EVERY_;  // DMA k goes out in tap EVERY * k: four waves issuing 64-line DMAs in the same tap ask the
@@ -755,14 +765,16 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
 
     // tile-invariant lane part of the four DMA ranges of a plane: voxel offset from the brick origin (24 bits) | the
     // brick faces the voxel lies on << 24 (bit 6: a padding slot beyond the brick)
-    unsigned dma_pk[4];
+    constexpr int NPK = G::INTERLEAVED ? 8 : 4;  // interleaved: DMA k covers voxels 32 (wave + 4 k) .. + 31, two lanes each
+    unsigned dma_pk[NPK];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int bv = (wave + 4 * k) * 64 + lane;
+    for (int k = 0; k < NPK; ++k) {
+        const int bv = G::INTERLEAVED ? (wave + 4 * k) * 32 + (lane >> 1) : (wave + 4 * k) * 64 + lane;
         const int bz = bv / (IX * IY), rr = bv - bz * (IX * IY), by = rr / IX, bx = rr - by * IX;
         const int face = (bz == 0) | ((bz == G::IZ - 1) << 1) | ((by == 0) << 2) | ((by == IY - 1) << 3) | ((bx == 0) << 4) | ((bx == IX - 1) << 5);
         dma_pk[k] = bv < G::BV ? (unsigned)(((bz * p.Hi + by) * p.Wi + bx) | (face << 24)) : (64u << 24);
     }
+    const unsigned lane_half16 = (lane & 1) * 16;
     auto dma = [&](const TileCoord &tc, int faces, int ch, auto k_c, char *buf) {
         constexpr int k = decltype(k_c)::value;
         const int cglob = ch * 16;
@@ -771,19 +783,25 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
         // wave-uniform part (SALU): the brick origin voxel, which may lie one voxel outside the tensor
         src += ((((long)tc.n * p.Di + (tc.oz0 - 1)) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1)) * (long)Csrc + coff;
-        unsigned pk = dma_pk[k & 3];
+        unsigned pk = dma_pk[G::INTERLEAVED ? k : (k & 3)];
         asm volatile("" : "+v"(pk));
         bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
         unsigned off = __umul24(pk & 0xffffffu, (unsigned)(Csrc * 2));  // bytes (< 2^32: host check)
+        if constexpr (G::INTERLEAVED) off += lane_half16;                 // odd lanes: channels 8..15 of the same voxel
         const char *gin = (const char *)src + off;
         asm volatile("" : "+v"(gin));  // (computed for every lane: left to itself the compiler branches around it, and a basic-block
                                        //  boundary between the MFMAs of a tap makes it wait for every outstanding LDS read there)
         const char *g = inside ? gin : (const char *)p.zeros;  // the zero page holds both planes' pieces
         asm volatile("" : "+v"(g));
-        // plane 1 = channels 8..15: the instruction's immediate is added to the global AND the LDS address
-        char *dst = buf + (k >> 2) * G::PLANE_BYTES + (wave + 4 * (k & 3)) * 1024 - (k >> 2) * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst,
-                                         16, (k >> 2) * 16, 0);
+        if constexpr (G::INTERLEAVED) {
+            char *dst = buf + (wave + 4 * k) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        } else {
+            // plane 1 = channels 8..15: the instruction's immediate is added to the global AND the LDS address
+            char *dst = buf + (k >> 2) * G::PLANE_BYTES + (wave + 4 * (k & 3)) * 1024 - (k >> 2) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst,
+                                             16, (k >> 2) * 16, 0);
+        }
     };
 
     // INAFF: this lane's piece k of a brick buffer, read back / normalised and written in place (see above the kernel)
@@ -795,25 +813,26 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     auto aff_bases = [&](char *buf, const TileCoord &tc, int ch, unsigned &pb, unsigned &ta, unsigned &tb) {
         pb = (unsigned)(size_t)(lds_char_t *)buf + wave * 1024 + lane * 16;
         ta = (unsigned)(size_t)(lds_char_t *)(lds_raw + G::TAB_OFF) + (tc.n * p.C0 + ch * 16) * 2;
+        if constexpr (G::INTERLEAVED) ta += lane_half16;  // (odd lanes hold channels 8..15)
         tb = ta + tab_n * 2;
         asm volatile("" : "+v"(pb), "+v"(ta), "+v"(tb));
     };
     auto aff_read = [&](unsigned pb, auto k_c) {
         constexpr int k = decltype(k_c)::value;
-        return *(const __attribute__((address_space(3))) f32x4 *)(pb + (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024);
+        return *(const __attribute__((address_space(3))) f32x4 *)(pb + (G::INTERLEAVED ? 4 * k * 1024 : (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024));
     };
     auto aff_apply = [&](int faces, auto k_c, unsigned pb, unsigned ta, unsigned tb, f32x4 raw) {
         constexpr int k = decltype(k_c)::value;
-        const f16x8 sc = *(const __attribute__((address_space(3))) f16x8 *)(ta + (k >> 2) * 16);
-        const f16x8 sh = *(const __attribute__((address_space(3))) f16x8 *)(tb + (k >> 2) * 16);
+        const f16x8 sc = *(const __attribute__((address_space(3))) f16x8 *)(ta + (G::INTERLEAVED ? 0 : (k >> 2) * 16));
+        const f16x8 sh = *(const __attribute__((address_space(3))) f16x8 *)(tb + (G::INTERLEAVED ? 0 : (k >> 2) * 16));
         f16x8 y = __builtin_elementwise_fma(__builtin_bit_cast(f16x8, raw), sc, sh);
         const f16x8 sl8 = {slope_in, slope_in, slope_in, slope_in, slope_in, slope_in, slope_in, slope_in};
         y = __builtin_elementwise_max(y, y * sl8);
-        unsigned pk = dma_pk[k & 3];
+        unsigned pk = dma_pk[G::INTERLEAVED ? k : (k & 3)];
         asm volatile("" : "+v"(pk));
         const bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
         // (padding follows the norm: out-of-volume pieces stay the zeros the DMA wrote; their result goes to the junk area)
-        unsigned dst = inside ? pb + ((k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024) : aff_junk;
+        unsigned dst = inside ? pb + (G::INTERLEAVED ? 4 * k * 1024 : (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024) : aff_junk;
         asm volatile("" : "+v"(dst));
         *(__attribute__((address_space(3))) f32x4 *)dst = __builtin_bit_cast(f32x4, y);
     };
@@ -824,7 +843,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         const int v = (wave * MF + mf) * 32 + l31;
-        a_base[mf] = half * G::PLANE_BYTES + (((v >> 6) * IY + ((v >> 3) & 7)) * IX + (v & 7)) * 16;
+        a_base[mf] = G::INTERLEAVED ? (((v >> 6) * IY + ((v >> 3) & 7)) * IX + (v & 7)) * 32 + half * 16
+                                    : half * G::PLANE_BYTES + (((v >> 6) * IY + ((v >> 3) & 7)) * IX + (v & 7)) * 16;
     }
     const int co_blk = (int)blockIdx.y * NF * 32;
     const char *wblk = (const char *)(p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512));
@@ -946,7 +966,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                         if constexpr (tap + 1 < 27) {
                             constexpr int nt = tap + 1;
                             constexpr int dz = nt / 9, rr = nt - dz * 9, dy = rr / 3, dx = rr - dy * 3;
-                            constexpr int off = ((dz * IY + dy) * IX + dx) * 16;
+                            constexpr int off = ((dz * IY + dy) * IX + dx) * G::VOX_BYTES;
 #pragma unroll
                             for (int m = 0; m < MF; ++m) a[(tap + 1) & 1][m] = *(lds_cf16x8 *)(ab[m] + off);
                         }
