@@ -1074,7 +1074,13 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                 const f32x4 v = *(const __attribute__((address_space(3))) f32x4 *)(rd + j * 8 * G::EPI_PITCH);
                 const char *row = (const char *)(obase + ((size_t)(j >> 3) * p.Ho + (j & 7)) * p.Wo * p.Cout);
                 const unsigned lo = lane_off;
-                asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(lo), "v"(v), "s"(row) : "memory");
+#ifndef MI355_H16_SC1
+#define MI355_H16_SC1 1
+#endif
+                // sc1: the output lines leave the XCD's L2 with the store - nothing on this XCD reads them again, and kept there
+                // they evict the brick lines whose next 32 bytes the next channel chunk is about to fetch
+                if constexpr (MI355_H16_SC1 != 0) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(lo), "v"(v), "s"(row) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(lo), "v"(v), "s"(row) : "memory");
             });
             if constexpr (STATS) {
                 __syncthreads();
