@@ -292,7 +292,9 @@ __global__ __launch_bounds__(256) void tconv2_f16_mfma_kernel(const _Float16 *__
 }
 
 // Version 2 (same decomposition as tconv2_f32_mfma_v2_kernel): 128 voxels x 32 couts x 8 parities per workgroup.
-__global__ __launch_bounds__(256) void tconv2_f16_mfma_v2_kernel(const _Float16 *__restrict__ in,
+// Two workgroups per CU (round 2): left to itself hipcc spread this kernel over 146 VGPRs + 128 AGPRs, one wave per SIMD, and a
+// workgroup that loads, computes and stores in sequence had nothing to overlap with (137 -> 111 us per launch; three per CU spill).
+__global__ __launch_bounds__(256, 2) void tconv2_f16_mfma_v2_kernel(const _Float16 *__restrict__ in,
                                                                 const _Float16 *__restrict__ wp, _Float16 *out, int M,
                                                                 int Cin, int Cout, int D, int H, int W, FastDiv divW,
                                                                 FastDiv divH, FastDiv divD) {
