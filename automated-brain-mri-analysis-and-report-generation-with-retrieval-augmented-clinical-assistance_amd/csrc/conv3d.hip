@@ -1174,9 +1174,11 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
             const unsigned t_stride = (unsigned)(8 * p.Cout);
             const f32x2 b01 = {bias[0], bias[1]}, b23 = {bias[2], bias[3]};
             // (a scalar across the tile loop; the vector copy is made here)
-            const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.act == ACT_LRELU ? p.slope : 1.0f)));
-            f32x2 slope2 = {slope, slope};
-            asm volatile("" : "+v"(slope2));
+            // (the scalar is laundered, not the vector: {slope, slope} built from a loop-invariant scalar is itself loop-invariant - hipcc
+            //  made the pair at kernel entry, spilled it, and this epilogue began with a cache-cold scratch reload and a vmcnt(0))
+            float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.act == ACT_LRELU ? p.slope : 1.0f)));
+            asm volatile("" : "+s"(slope));
+            const f32x2 slope2 = {slope, slope};
             bool xok[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) xok[t] = cur.ox0 + 8 * t + srow < p.Wo;
@@ -1232,7 +1234,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     hq[c][g] = c < p.head_ncls ? *(const f32x4 *)(p.head_w + c * p.Cout + (int)blockIdx.y * 32 + 8 * g + co_l) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.act == ACT_LRELU ? p.slope : 1.0f)));
+            float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.act == ACT_LRELU ? p.slope : 1.0f)));
+            asm volatile("" : "+s"(slope));  // (see the plain epilogue: the vector pair must not become a tile-loop invariant)
             const f32x2 slope2 = {slope, slope};
             f32x2 part[4][KMAX];
 #pragma unroll
