@@ -273,10 +273,11 @@ print("OK", worst)
 
 
 @pytest.mark.parametrize("env", [{"MI355_WINOGRAD": "0"}, {"MI355_WINOGRAD": "1"}, {"MI355_S2_DMA": "0", "MI355_SPLITK": "0"},
-                                 {"MI355_CONV_IMPL": "0"}])
+                                 {"MI355_CONV_IMPL": "0"}, {"MI355_F16_DMA": "0"}])
 def test_conv_dispatch_switches_keep_working(amd, gpu, env):
     """The A/B switches select the older kernels behind the same entry points (direct instead of Winograd, simple
-    instead of the stride-2 DMA / split-K kernels); they are read once per process, so each setting runs in a child."""
+    instead of the stride-2 DMA / split-K kernels, register-staged instead of LDS-DMA in fp16); they are read once per
+    process, so each setting runs in a child."""
     import os
     import subprocess
     import sys
