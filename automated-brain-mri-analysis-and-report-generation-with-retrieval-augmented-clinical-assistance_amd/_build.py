@@ -3,12 +3,15 @@
 Each ``csrc/*.hip`` is compiled to an object file in parallel (``hipcc -c``), then linked into
 ``<repo>/lib/libmi355_nnunet.so`` (a short in-tree path: the package directory's prescribed name is ~100 characters
 long, and tools that list ``/proc/<pid>/maps`` truncate such lines); objects are rebuilt only when their source or a
-header changed.  Concurrent builders (torch.distributed ranks, parallel pipeline processes) serialise on an flock and
+header changed.  "Changed" is decided by content, not by time stamps: the library and every object carry a digest of
+what they were built from (``*.digest`` beside them), so a snapshot that shuffles mtimes can neither force a rebuild nor -
+the dangerous direction - let a stale library pass for a fresh one.  Concurrent builders (torch.distributed ranks, parallel pipeline processes) serialise on an flock and
 link through a per-process temporary name, so nobody ever loads a half-written library.
 """
 from __future__ import annotations
 
 import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -36,12 +39,32 @@ def _headers():
     return list(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "mi355_nnunet.h"]
 
 
+def _digest(paths) -> str:
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in sorted(paths, key=lambda q: q.name):
+        h.update(p.name.encode() + b"\0" + p.read_bytes() + b"\0")
+    return h.hexdigest()
+
+
+def _object_digest(src: Path) -> str:
+    return _digest([src] + _headers())
+
+
+def _library_digest() -> str:
+    return _digest([CSRC / s for s in SOURCES] + _headers())
+
+
+def _recorded(artefact: Path) -> str:
+    f = artefact.with_name(artefact.name + ".digest")
+    return f.read_text().strip() if f.exists() else ""
+
+
+def _record(artefact: Path, digest: str):
+    artefact.with_name(artefact.name + ".digest").write_text(digest + "\n")
+
+
 def needs_build() -> bool:
-    if not LIB_PATH.exists():
-        return True
-    t = LIB_PATH.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + _headers()
-    return any(p.stat().st_mtime > t for p in deps)
+    return not LIB_PATH.exists() or _recorded(LIB_PATH) != _library_digest()
 
 
 @contextmanager
@@ -76,14 +99,19 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             return LIB_PATH
         hipcc = find_hipcc()
         OBJ_DIR.mkdir(parents=True, exist_ok=True)
-        hdr_time = max(p.stat().st_mtime for p in _headers())
+        lib_digest = _library_digest()  # (taken before compiling: an edit during the build leaves the digest stale, not wrong)
         jobs = []
         for s in SOURCES:
             src, obj = CSRC / s, OBJ_DIR / (s + ".o")
-            if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_time):
-                jobs.append((src, obj))
+            d = _object_digest(src)
+            if force or not obj.exists() or _recorded(obj) != d:
+                jobs.append((src, obj, d))
+
+        def compile_one(j):
+            _compile(hipcc, j[0], j[1], verbose)
+            _record(j[1], j[2])
         with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
-            list(pool.map(lambda j: _compile(hipcc, j[0], j[1], verbose), jobs))
+            list(pool.map(compile_one, jobs))
         tmp = LIB_PATH.with_suffix(f".so.{os.getpid()}.tmp")
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(OBJ_DIR / (s + ".o")) for s in SOURCES], "-o", str(tmp)]
         if verbose:
@@ -93,6 +121,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             tmp.unlink(missing_ok=True)
             raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
         os.replace(tmp, LIB_PATH)
+        _record(LIB_PATH, lib_digest)
     return LIB_PATH
 
 
