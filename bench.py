@@ -184,7 +184,7 @@ def roofline_of(prof, dtype, traffic_ok):
     achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if traffic_ok and os.path.exists(pmc_file):  # the committed PMC passes were taken on the default workload's launch sizes
+    if traffic_ok and os.path.exists(pmc_file):  # the committed PMC passes were taken on these workloads' launch sizes (config 2 f32, config 3 f16)
         try:
             traffic = json.load(open(pmc_file)).get(dom_name, {}).get("hbm_bytes_per_launch")
         except Exception:
@@ -284,7 +284,7 @@ def run_single_volume(ctx, args, config, dtype, steps, warmup, data, props, step
                        "models": [m[0] for m in wl["models"]], "crop": list(data.shape[1:]),
                        "sharding": "cases (one volume per rank per step)", "tflop_per_volume": round(flops_per_volume / 1e12, 3)},
                sustained_tflops_per_gpu=round(flops_per_volume * steps / elapsed / 1e12, 2),
-               roofline=roofline_of(prof, dtype, traffic_ok=(config == 2 and dtype == "f32" and not args.batch_tiles)),
+               roofline=roofline_of(prof, dtype, traffic_ok=((config == 2 and dtype == "f32") or (config == 3 and dtype == "f16")) and not args.batch_tiles),
                kernels=kernel_table(prof),
                label_histogram=ctx.torch.bincount(seg.flatten().to(ctx.torch.int64), minlength=4).tolist(),
                speedup_vs_nominal_5min=round(300.0 / (elapsed / steps), 1))
