@@ -26,6 +26,7 @@ EXPORTS = [
     "mi355_zscore_masked", "mi355_conv3d_ndhwc", "mi355_tconv3d_ndhwc", "mi355_profile_enable",
     "mi355_profile_read", "mi355_conv3d_ndhwc_f16", "mi355_tconv3d_ndhwc_f16",
     "mi355_label_remap", "mi355_label_confusion", "mi355_cosine_topk", "mi355_crop_mask", "mi355_label_stats",
+    "mi355_last_conv_kernel",
 ]
 
 
@@ -92,6 +93,7 @@ def load():
     lib = C.CDLL(str(path))
     vp = C.c_void_p
     lib.mi355_last_error.restype = C.c_char_p
+    lib.mi355_last_conv_kernel.restype = C.c_char_p
     lib.mi355_unet_create.argtypes = [C.POINTER(UNetDesc), C.POINTER(vp)]
     lib.mi355_unet_destroy.argtypes = [vp]
     lib.mi355_unet_flops.argtypes = [vp, C.c_int, C.c_int, C.c_int]

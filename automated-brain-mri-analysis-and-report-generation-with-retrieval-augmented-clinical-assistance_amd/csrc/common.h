@@ -87,13 +87,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // associative.  Rounding each partial to a multiple of a fixed quantum q first makes every addition EXACT (all operands and
 // all partial totals are multiples of q, and a double holds multiples of q exactly up to 2^53 q), so the total does not
 // depend on the order: run-to-run and rank-to-rank bit-identical statistics without a second pass.  q scales with the
-// number of voxels V the statistic runs over (2^lv <= V): 2^(lv-36) for sum x, 2^(lv-30) for sum x^2 - exact while
-// |mean x| < 1.3e5 and rms x < 2.9e3 whatever the layer size, and worth a relative 2^-30 of a unit-variance total.
-// Beyond those magnitudes the additions merely stop being exact (the statistics stay correct to fp64 rounding; only the
-// order independence is lost).
+// number of voxels V the statistic runs over (2^lv <= V): 2^(lv-40) for sum x, 2^(lv-44) for sum x^2.
+//   * What the rounding costs: a workgroup's partial covers >= 128 voxels, so there are at most V / 128
+//     partials and the worst case - every partial off by q / 2 in the same direction - moves mean x by q / 256 = 2^(lv-48)
+//     and mean x^2 by 2^(lv-52): 7.5e-9 and 4.7e-10 at a 128^3 patch (lv = 21), nothing against eps = 1e-5 however small
+//     the channel's pre-norm rms is (round 2's quantum for sum x^2, 2^(lv-30) = 2e-3 at that patch, zeroed the variance
+//     of a channel with rms 1e-3: every partial rounded to 0).
+//   * Where the additions stay exact (all totals below 2^53 q): |mean x| < 8192 and rms x < 16.  Beyond those
+//     magnitudes the additions merely stop being exact: the statistics stay correct to fp64 rounding, only the order
+//     independence is lost.
 __device__ __forceinline__ double quantise_partial(double v, int k, long voxels) {
     const int lv = 63 - __clzll((unsigned long long)(voxels > 0 ? voxels : 1));
-    const int e = lv - (k == 0 ? 36 : 30);
+    const int e = lv - (k == 0 ? 40 : 44);
     return ldexp(rint(ldexp(v, -e)), e);
 }
 

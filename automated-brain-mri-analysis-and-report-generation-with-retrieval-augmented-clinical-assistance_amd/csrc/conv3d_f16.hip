@@ -1346,6 +1346,11 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1>, a, grid, lds_bytes, s, &attr[1]);
         return launch_h(conv3_f16_mfma_pipe_kernel<2, 2>, a, grid, lds_bytes, s, &attr[2]);
     }
+    if (st == 2 && use_pipe_h()) {  // round 3: Cout % 128 == 0 on whole 4 x 4 x 8 output tiles -> conv3d_f16_s2.hip
+        bool taken = false;
+        MI355_TRY(conv3d_f16_s2dma(w, c, s, kernel_name, &taken));
+        if (taken) return MI355_OK;
+    }
     if (st == 2 && w.nf == 2 && !c.head_out && use_pipe_h()) {
         // round 2: the pipelined kernel with STRIDE = 2 (register-staged, two lanes per voxel) for the large stride-2 launches
         static int s2pipe = -1;  // MI355_S2_DMA=0: the one-tile-per-workgroup kernel instead (the switch of the f32 stride-2 kernel)

@@ -203,13 +203,25 @@ constexpr int HEAD_MAX_CLS = 8;
 // One thread per voxel: the whole channel vector of the voxel is read with 16-B loads (every byte of every
 // line is used, consecutive lanes = consecutive voxels), the ncls x C head weights are wave-uniform (scalar loads),
 // no cross-lane traffic.  The aggregate / normaliser read-modify-writes are then fully coalesced along x.
-template <typename T>
+// NORM: the feature map is the RAW output of the last decoder conv and its Instance/GroupNorm (+ LeakyReLU) is applied here,
+// per channel with this sample's scale / shift (wave-uniform: scalar loads) - generic_UNet.py:62-72 is one expression,
+// lrelu(instnorm(conv(x))), and this kernel reads every feature exactly once anyway (round 3: removes the norm_apply pass
+// over the widest-resolution tensor of the decoder).
+template <typename T, bool NORM>
 __device__ __forceinline__ void head_dot(const T *feat_vox, const float *__restrict__ w, const float *__restrict__ b,
-                                         int C, int ncls, float *logit) {
+                                         int C, int ncls, float *logit, const float *__restrict__ sc = nullptr,
+                                         const float *__restrict__ sh = nullptr, float nslope = 1.0f) {
 #pragma unroll
     for (int k = 0; k < HEAD_MAX_CLS; ++k) logit[k] = (k < ncls) ? b[k] : 0.f;
     for (int c = 0; c < C; c += 4) {
-        const f32x4 f = load4<T>(feat_vox + c);
+        f32x4 f = load4<T>(feat_vox + c);
+        if constexpr (NORM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = fmaf(f[j], sc[c + j], sh[c + j]);
+                f[j] = fmaxf(y, y * nslope);  // nslope = 1: no activation (max(y, y) = y)
+            }
+        }
 #pragma unroll
         for (int k = 0; k < HEAD_MAX_CLS; ++k)
             if (k < ncls) {
@@ -219,29 +231,35 @@ __device__ __forceinline__ void head_dot(const T *feat_vox, const float *__restr
     }
 }
 
-template <typename T>
+template <typename T, bool NORM>
 __global__ void head_logits_kernel(const T *feat, const float *w, const float *b, int C, int ncls,
-                                   int64_t V, int64_t total, float *logits) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+                                   int64_t V, float *logits, FeatNorm fn) {
+    // (blockIdx.y = sample: the per-sample scale / shift rows stay wave-uniform)
+    const int64_t n = blockIdx.y;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = n * V + v;
         float lg[HEAD_MAX_CLS];
-        head_dot<T>(feat + i * C, w, b, C, ncls, lg);
-        const int64_t n = i / V, v = i - n * V;
+        head_dot<T, NORM>(feat + i * C, w, b, C, ncls, lg, NORM ? fn.scale + n * C : nullptr, NORM ? fn.shift + n * C : nullptr, fn.slope);
 #pragma unroll
         for (int k = 0; k < HEAD_MAX_CLS; ++k)
             if (k < ncls) logits[(n * ncls + k) * V + v] = lg[k];
     }
 }
 
-int head_logits(const HeadWeights &w, const void *feat, int dtype, int N, int64_t V, float *logits, hipStream_t s) {
-    const int64_t total = (int64_t)N * V;
-    int64_t blocks = (total + 255) / 256;
+template <typename T>
+static void launch_head_logits(const HeadWeights &w, const T *feat, int N, int64_t V, float *logits, const FeatNorm &fn, hipStream_t s) {
+    int64_t blocks = (V + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    if (dtype == MI355_F16)
-        hipLaunchKernelGGL(head_logits_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, (const _Float16 *)feat,
-                           w.w_dev, w.b_dev, w.cin, w.ncls, V, total, logits);
+    if (fn.scale)
+        hipLaunchKernelGGL((head_logits_kernel<T, true>), dim3((unsigned)blocks, N), dim3(256), 0, s, feat, w.w_dev, w.b_dev, w.cin, w.ncls, V, logits, fn);
     else
-        hipLaunchKernelGGL(head_logits_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float *)feat, w.w_dev,
-                           w.b_dev, w.cin, w.ncls, V, total, logits);
+        hipLaunchKernelGGL((head_logits_kernel<T, false>), dim3((unsigned)blocks, N), dim3(256), 0, s, feat, w.w_dev, w.b_dev, w.cin, w.ncls, V, logits, fn);
+}
+
+int head_logits(const HeadWeights &w, const void *feat, int dtype, int N, int64_t V, float *logits, hipStream_t s, const FeatNorm &fn) {
+    MI355_REQUIRE(N >= 1 && N <= 65535, "head_logits: %d samples", N);
+    if (dtype == MI355_F16) launch_head_logits<_Float16>(w, (const _Float16 *)feat, N, V, logits, fn, s);
+    else launch_head_logits<float>(w, (const float *)feat, N, V, logits, fn, s);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
@@ -255,10 +273,10 @@ struct MirrorList {
 //   result = sum_m  mult * flip_back(nonlin(net(flip_m(x))))      mult = 1/n_mirrors, m in list order
 //   result *= gaussian ; aggregated[:, tile] += result ; normaliser[tile] += gaussian
 // feat holds the last decoder feature map of the n_mirrors forwards of this tile.
-template <typename T>
+template <typename T, bool NORM>
 __global__ void head_aggregate_kernel(const T *feat, const float *w, const float *b, int C, int ncls,
                                       MirrorList ml, int P0, int P1, int P2, int nonlin, const float *gauss,
-                                      float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0) {
+                                      float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, FeatNorm fn) {
     const int64_t PV = (int64_t)P0 * P1 * P2;
     const int64_t ZYXp = (int64_t)Zp * Yp * Xp;
     const float mult = 1.0f / (float)ml.n;
@@ -276,7 +294,9 @@ __global__ void head_aggregate_kernel(const T *feat, const float *w, const float
             const int sx = (m & 4) ? P2 - 1 - px : px;
             const int64_t sv = ((int64_t)sz * P1 + sy) * P2 + sx;
             float lg[HEAD_MAX_CLS];
-            head_dot<T>(feat + ((int64_t)mi * PV + sv) * C, w, b, C, ncls, lg);
+            // (fn.scale / fn.shift already point at this tile's first sample)
+            head_dot<T, NORM>(feat + ((int64_t)mi * PV + sv) * C, w, b, C, ncls, lg, NORM ? fn.scale + mi * C : nullptr,
+                              NORM ? fn.shift + mi * C : nullptr, fn.slope);
             if (nonlin == MI355_NONLIN_SIGMOID) {
 #pragma unroll
                 for (int k = 0; k < HEAD_MAX_CLS; ++k) if (k < ncls) lg[k] = 1.0f / (1.0f + expf(-lg[k]));
@@ -302,24 +322,37 @@ __global__ void head_aggregate_kernel(const T *feat, const float *w, const float
     }
 }
 
+template <typename T>
+static void launch_head_aggregate(const HeadWeights &w, const T *feat, const MirrorList &ml, int P0, int P1, int P2, int nonlin,
+                                  const float *gauss, float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0,
+                                  const FeatNorm &fn, hipStream_t s) {
+    const int64_t PV = (int64_t)P0 * P1 * P2;
+    int64_t blocks = (PV + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (fn.scale)
+        hipLaunchKernelGGL((head_aggregate_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, feat, w.w_dev, w.b_dev, w.cin,
+                           w.ncls, ml, P0, P1, P2, nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0, fn);
+    else
+        hipLaunchKernelGGL((head_aggregate_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, feat, w.w_dev, w.b_dev, w.cin,
+                           w.ncls, ml, P0, P1, P2, nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0, fn);
+}
+
 int head_aggregate(const HeadWeights &w, const void *feat, int dtype, int first_sample, const int *mirrors_host,
                    int n_mirrors, int P0, int P1, int P2, int nonlin, const float *gauss, float *agg,
-                   float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, hipStream_t s) {
+                   float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, hipStream_t s, const FeatNorm &fn_all) {
     MI355_REQUIRE(n_mirrors >= 1 && n_mirrors <= 8, "head_aggregate: %d mirrors", n_mirrors);
     MirrorList ml;
     ml.n = n_mirrors;
     for (int i = 0; i < 8; ++i) ml.m[i] = i < n_mirrors ? mirrors_host[i] : 0;
     const int64_t PV = (int64_t)P0 * P1 * P2;
-    int64_t blocks = (PV + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
+    FeatNorm fn = fn_all;  // rows of this tile's first sample
+    if (fn.scale) { fn.scale += (size_t)first_sample * w.cin; fn.shift += (size_t)first_sample * w.cin; }
     if (dtype == MI355_F16)
-        hipLaunchKernelGGL(head_aggregate_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s,
-                           (const _Float16 *)feat + (size_t)first_sample * PV * w.cin, w.w_dev, w.b_dev, w.cin, w.ncls, ml,
-                           P0, P1, P2, nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0);
+        launch_head_aggregate<_Float16>(w, (const _Float16 *)feat + (size_t)first_sample * PV * w.cin, ml, P0, P1, P2, nonlin, gauss, agg,
+                                        cnt, Zp, Yp, Xp, z0, y0, x0, fn, s);
     else
-        hipLaunchKernelGGL(head_aggregate_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s,
-                           (const float *)feat + (size_t)first_sample * PV * w.cin, w.w_dev, w.b_dev, w.cin, w.ncls, ml, P0,
-                           P1, P2, nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0);
+        launch_head_aggregate<float>(w, (const float *)feat + (size_t)first_sample * PV * w.cin, ml, P0, P1, P2, nonlin, gauss, agg, cnt,
+                                     Zp, Yp, Xp, z0, y0, x0, fn, s);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }

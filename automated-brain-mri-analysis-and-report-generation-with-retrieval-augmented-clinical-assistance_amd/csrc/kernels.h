@@ -84,6 +84,8 @@ struct ConvCallH {
 };
 bool conv3d_f16_fuses_input_norm(const ConvWeightsH &w, const ConvCallH &c);
 int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, const char **kernel_name = nullptr);
+// stride-2 LDS-DMA kernel (conv3d_f16_s2.hip): launches when the call fits it and says so in *taken
+int conv3d_f16_s2dma(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, const char **kernel_name, bool *taken);
 
 // ---------------------------------------------------------------- transposed conv k=2 s=2
 struct TConvWeights {
@@ -132,13 +134,21 @@ struct HeadWeights {
 };
 int head_weights_upload(const float *w_host, const float *b_host, int cin, int ncls, HeadWeights *out);
 void head_weights_free(HeadWeights *w);
+// The feature map handed to the head may be the RAW output of the last decoder conv: then scale / shift [N][C] (fp32) hold
+// its Instance/GroupNorm affine and the head applies act(x * scale + shift) per channel while it reads the features
+// (slope = 1: no activation).  scale == nullptr: the features are final.
+struct FeatNorm {
+    const float *scale = nullptr, *shift = nullptr;
+    float slope = 1.0f;
+};
 // feat [N][V][C] -> logits [N][ncls][V]
-int head_logits(const HeadWeights &w, const void *feat, int dtype, int N, int64_t V, float *logits, hipStream_t s);
+int head_logits(const HeadWeights &w, const void *feat, int dtype, int N, int64_t V, float *logits, hipStream_t s,
+                const FeatNorm &fn = FeatNorm());
 // One tile: result = sum_m (1/n_mirrors) * flip_back(nonlin(head(feat[first_sample+m])));
 // agg[c][tile] += result * gauss ; cnt[tile] += gauss (cnt may be null).
 int head_aggregate(const HeadWeights &w, const void *feat, int dtype, int first_sample, const int *mirrors_host,
                    int n_mirrors, int P0, int P1, int P2, int nonlin, const float *gauss, float *agg,
-                   float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, hipStream_t s);
+                   float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, hipStream_t s, const FeatNorm &fn = FeatNorm());
 // same as head_aggregate for forwards whose last conv already produced logits [n_samples][ncls][PV]
 int logits_aggregate(const float *logits, int ncls, int first_sample, const int *mirrors_host, int n_mirrors, int P0, int P1,
                      int P2, int nonlin, const float *gauss, float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0,

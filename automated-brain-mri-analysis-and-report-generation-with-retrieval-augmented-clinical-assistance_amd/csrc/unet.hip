@@ -19,6 +19,7 @@
 namespace mi355 {
 
 static thread_local std::string g_last_error;
+static thread_local std::string g_last_conv_kernel;  // mi355_last_conv_kernel(): which instantiation a single-op conv call ran
 
 void set_error(const char *fmt, ...) {
     char buf[1024];
@@ -356,8 +357,12 @@ static bool can_defer_norm(const mi355_unet *net, const ConvLayer &L, const Conv
 // If the last decoder block has no run-time normalisation (BN folded / no norm) and its Cout fits one workgroup, the
 // 1x1x1 head is fused into its epilogue: *is_logits = true and *feat points at fp32 logits [N][ncls][V] (written to
 // logits_target when given, else into the arena); the 32-channel feature map is then never written nor re-read.
+// head_norm (round 3): when non-null and the last decoder block carries a run-time Instance/GroupNorm, that block's
+// normalisation (+ activation) is NOT applied to the returned feature map: *head_norm receives its scale / shift and the
+// caller's head kernel applies them while reading the features (head_logits / head_aggregate take a FeatNorm).
 static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H, int W, const void **feat,
-                            int *feat_c, hipStream_t s, bool *is_logits = nullptr, float *logits_target = nullptr) {
+                            int *feat_c, hipStream_t s, bool *is_logits = nullptr, float *logits_target = nullptr,
+                            FeatNorm *head_norm = nullptr) {
     const int np = net->num_pool;
     const bool f16 = net->dtype == MI355_F16;
     auto buf = [&](int k, int l) { return (void *)(net->arena + pl.off[k][l]); };
@@ -417,13 +422,21 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
             if (last && fuse && !L.runtime_norm && !L.post_affine && has_pack && L.cout == 32 * lnf && net->head.ncls <= 4 &&
                 net->head.cin == L.cout && (!f16 || lnf == 1)) {
                 float *lg = logits_target ? logits_target : (float *)out;
-                MI355_TRY(run_block(net, pl, L, in0, C0, in1, C1, N, Dl, Hl, Wl, nullptr, s, lg));
+                MI355_TRY(run_block(net, pl, L, in0, C0, in1, C1, N, Dl, Hl, Wl, nullptr, s, lg, false, pending_d));  // (a pending norm is refused loudly by the fused-head conv: ADVICE r2)
                 *is_logits = true;
                 *feat = lg; *feat_c = net->head.ncls;
                 return MI355_OK;
             }
-            const bool defer = i + 1 < net->dec[u].size() && can_defer_norm(net, L, net->dec[u][i + 1], N, Dl, Hl, Wl);
+            static int fuse_norm = -1;
+            if (fuse_norm < 0) { const char *e = getenv("MI355_FUSE_NORM"); fuse_norm = (e && e[0] == '0') ? 0 : 1; }
+            const bool to_head = fuse_norm && head_norm && L.runtime_norm && (u == np - 1) && (i + 1 == net->dec[u].size());
+            const bool defer = to_head || (i + 1 < net->dec[u].size() && can_defer_norm(net, L, net->dec[u][i + 1], N, Dl, Hl, Wl));
             MI355_TRY(run_block(net, pl, L, in0, C0, in1, C1, N, Dl, Hl, Wl, out, s, nullptr, defer, pending_d));
+            if (to_head) {
+                head_norm->scale = (const float *)(net->arena + pl.scale2_off);
+                head_norm->shift = (const float *)(net->arena + pl.shift2_off);
+                head_norm->slope = net->nonlin_first ? 1.0f : net->slope;  // ConvDropoutNonlinNorm: the activation came before the norm
+            }
             pending_d = defer;
             in0 = out; C0 = L.cout; in1 = nullptr; C1 = 0;
         }
@@ -556,7 +569,8 @@ static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X,
                                 (void *)(net->arena + pl.x0_off), net->dtype, s));
         }
         const void *feat; int fc; bool is_logits = false;
-        MI355_TRY(forward_features(net, pl, (int)samples.size(), g.P[0], g.P[1], g.P[2], &feat, &fc, s, &is_logits));
+        FeatNorm head_norm;
+        MI355_TRY(forward_features(net, pl, (int)samples.size(), g.P[0], g.P[1], g.P[2], &feat, &fc, s, &is_logits, nullptr, &head_norm));
         MI355_REQUIRE(is_logits || fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
         for (int i = 0; i < nb; ++i) {
             const TileDesc &td = g.tiles[mine[b0 + i]];
@@ -572,7 +586,7 @@ static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X,
                          pv * ((net->dtype == MI355_F16 ? 2.0 : 4.0) * nm * fc + 4.0 * (2.0 * net->num_classes + 3.0)));
             MI355_TRY(head_aggregate(net->head, feat, net->dtype, i * nm, g.mirrors.data(), nm, g.P[0], g.P[1], g.P[2], o.nonlin,
                                      use_gauss ? net->gauss_dev : nullptr, agg, (cnt && world == 1) ? cnt : nullptr,
-                                     g.Zp[0], g.Zp[1], g.Zp[2], td.z0, td.y0, td.x0, s));
+                                     g.Zp[0], g.Zp[1], g.Zp[2], td.z0, td.y0, td.x0, s, head_norm));
         }
     }
     return MI355_OK;
@@ -582,6 +596,7 @@ static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X,
 
 // =============================================================================== C ABI
 extern "C" const char *mi355_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *mi355_last_conv_kernel(void) { return g_last_conv_kernel.c_str(); }
 extern "C" int mi355_version(void) { return 100; }
 extern "C" int mi355_device_count(void) {
     int n = 0, good = 0;
@@ -693,10 +708,11 @@ extern "C" int mi355_unet_forward(mi355_unet_t net, const float *x_dev, int n, i
     const int64_t V = (int64_t)d * h * w;
     MI355_TRY(nchw_to_ndhwc(x_dev, n, net->in_channels, V, net->cin_pad, (void *)(net->arena + pl.x0_off), net->dtype, s));
     const void *feat; int fc; bool is_logits = false;
-    MI355_TRY(forward_features(net, pl, n, d, h, w, &feat, &fc, s, &is_logits, logits_dev));
+    FeatNorm head_norm;
+    MI355_TRY(forward_features(net, pl, n, d, h, w, &feat, &fc, s, &is_logits, logits_dev, &head_norm));
     if (is_logits) return MI355_OK;  // the last conv wrote [n][ncls][V] straight into logits_dev
     MI355_REQUIRE(fc == net->head.cin, "head expects %d channels, decoder gives %d", net->head.cin, fc);
-    MI355_TRY(head_logits(net->head, feat, net->dtype, n, V, logits_dev, s));
+    MI355_TRY(head_logits(net->head, feat, net->dtype, n, V, logits_dev, s, head_norm));
     return MI355_OK;
 }
 
@@ -813,6 +829,7 @@ extern "C" int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w
         StemWeights sw;
         MI355_TRY(stem_weights_upload(weight_host, bias_host, cin, cout, MI355_F32, &sw));
         int rc = conv3d_stem(sw, x_dev, n, d, h, w, y_dev, nullptr, act, slope, (hipStream_t)stream);
+        g_last_conv_kernel = "conv3_stem_f32_kernel";
         hipError_t e = hipStreamSynchronize((hipStream_t)stream);
         stem_weights_free(&sw);
         if (rc == MI355_OK && e != hipSuccess) { set_error("stem conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
@@ -822,7 +839,9 @@ extern "C" int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w
     MI355_TRY(conv_weights_upload(weight_host, bias_host, cin, cin, cout, stride, impl == 1, &cw));
     ConvCall c;
     c.in0 = x_dev; c.C0 = cin; c.N = n; c.Di = d; c.Hi = h; c.Wi = w; c.out = y_dev; c.act = act; c.slope = slope;
-    int rc = (impl == 1) ? conv3d_direct_f32(cw, c, (hipStream_t)stream) : conv3d_mfma_f32(cw, c, (hipStream_t)stream);
+    const char *kname = "conv3_direct_kernel";
+    int rc = (impl == 1) ? conv3d_direct_f32(cw, c, (hipStream_t)stream) : conv3d_mfma_f32(cw, c, (hipStream_t)stream, &kname);
+    g_last_conv_kernel = kname ? kname : "";
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     conv_weights_free(&cw);
     if (rc == MI355_OK && e != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
@@ -849,6 +868,7 @@ extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, in
         StemWeights sw;
         MI355_TRY(stem_weights_upload(weight_host, bias_host, cin, cout, MI355_F16, &sw));
         int rc = conv3d_stem(sw, x_dev, n, d, h, w, y_dev, nullptr, act, slope, (hipStream_t)stream);
+        g_last_conv_kernel = "conv3_stem_f16_kernel";
         hipError_t e = hipStreamSynchronize((hipStream_t)stream);
         stem_weights_free(&sw);
         if (rc == MI355_OK && e != hipSuccess) { set_error("stem conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
@@ -859,7 +879,9 @@ extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, in
     ConvCallH c;
     c.in0 = (const _Float16 *)x_dev; c.C0 = cin; c.N = n; c.Di = d; c.Hi = h; c.Wi = w; c.out = (_Float16 *)y_dev;
     c.act = act; c.slope = slope;
-    int rc = conv3d_mfma_f16(cw, c, (hipStream_t)stream);
+    const char *kname = nullptr;
+    int rc = conv3d_mfma_f16(cw, c, (hipStream_t)stream, &kname);
+    g_last_conv_kernel = kname ? kname : "";
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     conv_weights_free_f16(&cw);
     if (rc == MI355_OK && e != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }

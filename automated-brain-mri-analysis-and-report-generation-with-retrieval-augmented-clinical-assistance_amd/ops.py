@@ -123,6 +123,11 @@ def conv3d_ndhwc(x, weight, bias=None, stride=1, act=0, slope=0.01, impl="mfma")
     return y
 
 
+def last_conv_kernel() -> str:
+    """Kernel instantiation the last ``conv3d_ndhwc`` call of this thread ran on (test aid)."""
+    return (_lib.load().mi355_last_conv_kernel() or b"").decode()
+
+
 def tconv3d_ndhwc(x, weight):
     """Single ConvTranspose3d k=2 s=2 (test entry point). weight: numpy [Cin,Cout,2,2,2]."""
     import torch

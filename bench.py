@@ -8,10 +8,11 @@ Default workload = BASELINE.json configs[1]: one 4x240x240x155 volume, 128^3 pat
 model A (base 32, BatchNorm), 1 fold, fp32, no TTA -> 8 forwards per volume.  The default run also
 carries, inside the same JSON line, `secondary` blocks for BASELINE.json configs[2] (8-way TTA,
 models A + B, label ensemble) in fp16 and fp32 and an `end_to_end` block (host volume -> H2D ->
-crop -> z-score -> predict -> labels -> D2H).
+crop -> z-score -> predict -> labels -> D2H) and a `reference_setting` block: the reference's own per-case setting
+(5 folds x 2 models x 8-way TTA) in fp16 and fp32, one timed step each.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--dtype f32|f16]
-                    [--no-cpu-baseline] [--no-secondary]
+                    [--no-cpu-baseline] [--no-secondary] [--no-reference-setting]
 
 --config 4 = BASELINE.json configs[3]: a batch of 32 synthetic volumes (seeds 1000..1031), config-3
 settings, CASES sharded round-robin over the ranks (SURVEY.md 8e partitioning A, no data-path
@@ -39,6 +40,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP3
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, same guide
 PEAK_HBM_GBS = 8000.0
 PATCH = (128, 128, 128)
+DICE_GATE = 0.999  # BASELINE.json north_star: Dice against the reference CPU output >= 0.999
 # Winograd kernels execute fewer multiplies than the algorithmic (direct-convolution) count that `achieved` uses:
 # F(2,3) along y issues 2/3 of the direct MFMAs, F(2x2,3x3) over (z,y) 4/9; frac can therefore exceed 1 and
 # frac_executed = matrix-pipe utilisation is reported beside it.
@@ -64,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4), help="BASELINE.json config (1-based)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 and end-to-end blocks of the default run")
+    ap.add_argument("--no-reference-setting", action="store_true", help="skip the 5-fold x 2-model x TTA block of the default run")
     ap.add_argument("--batch-tiles", type=int, default=0)
     ap.add_argument("--cases", type=int, default=0, help="config 4: number of volumes in the batch (default 32)")
     ap.add_argument("--dtype", choices=("f32", "f16"), default=None, help="default: f32 for config 2, f16 for configs 3 and 4")
@@ -183,10 +186,13 @@ def roofline_of(prof, dtype, traffic_ok):
     avg_ms = dom["ms"] / dom["launches"]
     achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
     traffic = None
+    traffic_source = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if traffic_ok and os.path.exists(pmc_file):  # the committed PMC passes were taken on these workloads' launch sizes (config 2 f32, config 3 f16)
         try:
             traffic = json.load(open(pmc_file)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            if traffic is not None:  # (not measured in this run: the committed rocprofv3 --pmc passes of the same command)
+                traffic_source = "profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/collect_profiles.sh)"
         except Exception:
             traffic = None
     peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_F16_MFMA_TFLOPS
@@ -194,7 +200,7 @@ def roofline_of(prof, dtype, traffic_ok):
     conv_ms = sum(v["ms"] for k, v in prof.items() if v["flops"] > 0)
     conv_flops = sum(v["flops"] for v in prof.values())
     return dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                frac=round(achieved / peak, 4), traffic=traffic, executed_flop_ratio=round(ratio, 4),
+                frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, executed_flop_ratio=round(ratio, 4),
                 frac_executed=round(achieved * ratio / peak, 4), launches=dom["launches"], avg_launch_ms=round(avg_ms, 4),
                 algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3),
                 algorithmic_mb_per_launch=round(dom["bytes"] / dom["launches"] / 1e6, 2),
@@ -300,6 +306,47 @@ def run_single_volume(ctx, args, config, dtype, steps, warmup, data, props, step
     for n in nets:
         n.close()
     return res
+
+
+REFERENCE_FOLDS = 5  # run_brats2021_inference_singlethread.py:161 folds=(0, 1, 2, 3, 4)
+
+
+def run_reference_setting(ctx, dtype, data, props, steps_tbl):
+    """The reference's own per-case setting as ONE workload (run_brats2021_inference_singlethread.py:161,208-211,263-264):
+    two models x five folds x 8-way mirror TTA, fold-mean probabilities per model (:128), region labels, label-round
+    ensemble (:305).  Synthetic folds: seeds 7..11 (model A) and 8..12 (model B).  One untimed step (arena growth, first
+    launches), then one timed step."""
+    from brats_amd import predictor, ops
+    torch = ctx.torch
+    models = [[("A", 7 + k) for k in range(REFERENCE_FOLDS)], [("B", 8 + k) for k in range(REFERENCE_FOLDS)]]
+    nets = [build_nets(m, dtype) for m in models]
+    full = props["original_size_of_raw_data"]
+    lo = [b[0] for b in props["crop_bbox"]]
+    n_tiles = int(np.prod([len(s) for s in steps_tbl]))
+    flops = sum(n.flops(PATCH) for folds in nets for n in folds) * n_tiles * 8
+
+    def step():
+        segs = []
+        for folds in nets:
+            probs = predictor.predict_folds(folds, data, PATCH, 0.5, True, (0, 1, 2), True, "sigmoid")
+            segs.append(ops.regions_to_labels(probs, (1, 2, 3), lo, full))
+        return ops.label_ensemble(segs[0], segs[1])
+
+    step()
+    torch.cuda.synchronize(ctx.device)
+    t0 = time.perf_counter()
+    seg = step()
+    torch.cuda.synchronize(ctx.device)
+    dt = time.perf_counter() - t0
+    for folds in nets:
+        for n in folds:
+            n.close()
+    return dict(workload="the reference's per-case setting: models A + B x 5 folds each x 8-way mirror TTA, fold mean, region "
+                         "labels, label-round ensemble (run_brats2021_inference_singlethread.py:161,208-211,263-264)",
+                dtype=dtype, steps=1, warmup=1, forwards_per_volume=2 * REFERENCE_FOLDS * n_tiles * 8,
+                seconds_per_volume=round(dt, 3), volumes_per_s=round(1.0 / dt, 4), tflop_per_volume=round(flops / 1e12, 1),
+                sustained_tflops_per_gpu=round(flops / dt / 1e12, 1), speedup_vs_nominal_5min=round(300.0 / dt, 1),
+                label_histogram=torch.bincount(seg.flatten().to(torch.int64), minlength=4).tolist())
 
 
 def run_end_to_end(ctx, raw, steps=3):
@@ -421,6 +468,8 @@ def main(argv=None):
             r.pop("_flops_per_volume"); r.pop("_elapsed")
             secondary[f"config3_{dt}"] = r
         secondary["end_to_end"] = run_end_to_end(ctx, raw)
+        if not args.no_reference_setting:
+            secondary["reference_setting"] = {dt: run_reference_setting(ctx, dt, data, props, steps_tbl) for dt in ("f16", "f32")}
 
     if ctx.rank != 0:
         ctx.close()
@@ -455,6 +504,19 @@ def main(argv=None):
         out["secondary"] = secondary
     print(json.dumps(out))
     ctx.close()
+    # north_star gate: Dice of the GPU label map against the CPU oracle's on the same tile >= 0.999, for every parity block of
+    # this run; the line above is printed either way, a miss makes the run fail (the bench asserted nothing)
+    misses = []
+    blocks = [("main", out.get("parity_vs_cpu_ref"))] + [(k, v.get("parity_vs_cpu_ref")) for k, v in (secondary or {}).items() if isinstance(v, dict)]
+    for where, par in blocks:
+        if not par:
+            continue
+        for name, blk in (par.items() if "dice_wt_tc_et_mean" not in par else [("", par)]):
+            if blk["dice_wt_tc_et_mean"] < DICE_GATE:
+                misses.append(f"{where}{'/' + name if name else ''}: Dice {blk['dice_wt_tc_et_mean']} < {DICE_GATE}")
+    if misses:
+        print("PARITY GATE MISSED: " + "; ".join(misses), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

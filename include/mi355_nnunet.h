@@ -198,6 +198,10 @@ int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int ci
                            void *stream);
 int mi355_tconv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
                             int cout, void *y_dev, void *stream);
+/* Name of the kernel instantiation the calling thread's last mi355_conv3d_ndhwc / mi355_conv3d_ndhwc_f16 call dispatched
+ * (the names rocprofv3 and mi355_profile_read show).  Test aid: a parity case written for one kernel can assert that it
+ * ran on that kernel.  No reference counterpart (torch.nn.Conv3d, generic_UNet.py:56, has one implementation). */
+const char *mi355_last_conv_kernel(void);
 
 #ifdef __cplusplus
 }

@@ -170,8 +170,23 @@ F16_CONV_CASES = [
     (2, 4, 4, 4, 320, 320, 1, 1),    # bottleneck-sized launch
     (8, 32, 32, 32, 64, 64, 1, 1),   # Cout % 64 == 0, volume a whole number of 8^3 tiles, >= 512 tiles: the LDS-DMA kernel
     (2, 32, 64, 64, 48, 128, 1, 0),  # the same kernel: 3 chunks, two cout blocks, no activation
-    (3, 24, 40, 72, 16, 64, 1, 1),   # the same kernel: one chunk, odd tile counts (3 x 5 x 9), batch 3
+    (4, 24, 40, 72, 16, 64, 1, 1),   # the same kernel: one chunk, odd tile counts (3 x 5 x 9 -> linear tile order), 540 tiles (not a multiple of 8: uneven XCD split)
+    (2, 64, 64, 64, 32, 128, 2, 1),  # round 3: stride 2, Cout % 128 == 0, whole 4 x 4 x 8 output tiles -> conv3_f16_s2dma_kernel, 2 chunks
+    (2, 32, 32, 64, 64, 256, 2, 0),  # the same kernel: two cout blocks of 128, 4 chunks, no activation
+    (6, 24, 40, 48, 16, 128, 2, 1),  # the same kernel: one chunk, 3 x 5 x 3 tiles (linear tile order), 270 tiles (uneven XCD split), batch 6
 ]
+
+#: which kernel a case is written for (asserted through mi355_last_conv_kernel; ADVICE r2: a case that claims a kernel must run on it)
+F16_EXPECT_KERNEL = {
+    (8, 32, 32, 32, 64, 64, 1, 1): "conv3_f16_dma_kernel<false, false>",
+    (2, 32, 64, 64, 48, 128, 1, 0): "conv3_f16_dma_kernel<false, false>",
+    (4, 24, 40, 72, 16, 64, 1, 1): "conv3_f16_dma_kernel<false, false>",
+    (2, 64, 64, 64, 32, 128, 2, 1): "conv3_f16_s2dma_kernel<false>",
+    (2, 32, 32, 64, 64, 256, 2, 0): "conv3_f16_s2dma_kernel<false>",
+    (6, 24, 40, 48, 16, 128, 2, 1): "conv3_f16_s2dma_kernel<false>",
+    (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f16_mfma_pipe_kernel<1, 2, false, false, 2>",
+    (8, 8, 8, 8, 320, 320, 1, 1): "conv3_f16_mfma_kernel<1, 2, 2> split-K",
+}
 
 
 @pytest.mark.parametrize("case", F16_CONV_CASES)
@@ -185,10 +200,14 @@ def test_conv3d_f16_matches_torch(amd, gpu, case):
     b = _rand(rs, cout)
     ref = _ref_conv(x.astype(np.float32), wt.astype(np.float32), b, stride, act, 0.01)
     y = amd.ops.conv3d_ndhwc(torch.from_numpy(x).to(gpu), wt.astype(np.float32), b, stride=stride, act=act, slope=0.01)
+    ran = amd.ops.last_conv_kernel()
     y = y.float().cpu().numpy()
     assert y.shape == ref.shape
     err = np.abs(y - ref).max()
-    assert err <= 2e-3 * max(1.0, np.abs(ref).max()), f"max abs err {err}"
+    assert err <= 2e-3 * max(1.0, np.abs(ref).max()), f"max abs err {err} ({ran})"
+    import os
+    if case in F16_EXPECT_KERNEL and not any(k in os.environ for k in ("MI355_CONV_IMPL", "MI355_F16_DMA", "MI355_F16_S2", "MI355_S2_DMA", "MI355_SPLITK")):
+        assert ran == F16_EXPECT_KERNEL[case], ran
 
 
 def test_conv3d_f16_identity_asymmetric(amd, gpu):
