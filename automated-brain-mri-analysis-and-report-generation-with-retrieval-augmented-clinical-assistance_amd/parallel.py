@@ -1,9 +1,10 @@
 """Multi-GPU sharding of the path: one process per GPU, torch.distributed over RCCL/xGMI
 (backend "nccl" on ROCm; "gloo" in the CPU tests).  SURVEY.md 8e.
 
-* Partitioning A (throughput; BASELINE.json configs[3], bench.py): CASES are dealt round-robin to
-  ranks, every rank holds the weights, no data-path collective; an optional all_gather of the
-  uint8 label maps (8.9 MB each) brings results to every rank.
+* Partitioning A (throughput; BASELINE.json configs[3], bench.py): CASES are dealt to ranks - longest
+  first onto the least loaded rank when their tile counts are known (real crops run from 2 to 12
+  tiles), round-robin otherwise -, every rank holds the weights, no data-path
+  collective; an optional all_gather of the uint8 label maps (8.9 MB each) brings results to every rank.
 * Partitioning B (latency of ONE case): the tile list is dealt round-robin
   (``mi355_sw_partial``), each rank holds a Gaussian-weighted partial aggregate, and there is one
   exchange step: an all_gather of the partial aggregates (3 x Zp x Yp x Xp fp32, about 40 MB per
@@ -12,8 +13,9 @@
 """
 from __future__ import annotations
 
+import math
 import os
-from typing import List
+from typing import List, Optional, Sequence
 
 
 def init_distributed(backend: str = None):
@@ -34,11 +36,34 @@ def init_distributed(backend: str = None):
     return rank, world, local_rank
 
 
-def shard_cases(n_cases: int, rank: int, world: int) -> List[int]:
-    """Round-robin: case i goes to rank i % world."""
+def tiles_of_shape(shape_zyx: Sequence[int], patch_size: Sequence[int] = (128, 128, 128), step_size: float = 0.5) -> int:
+    """Sliding-window tiles of a (cropped) volume: per axis ceil((max(size, patch) - patch) / (patch * step)) + 1, the count
+    behind nnU-Net v1's ``_compute_steps_for_sliding_window`` - the cost of a case in forwards."""
+    n = 1
+    for s, p in zip(shape_zyx, patch_size):
+        n *= int(math.ceil((max(int(s), int(p)) - int(p)) / (int(p) * float(step_size)))) + 1
+    return n
+
+
+def shard_cases(n_cases: int, rank: int, world: int, weights: Optional[Sequence[float]] = None) -> List[int]:
+    """The case indices of ``rank``.  Without ``weights``: round-robin (case i goes to rank i % world).  With ``weights``
+    (one cost per case, e.g. its tile count): longest-processing-time-first - cases in descending cost (ties by index) each
+    go to the rank with the smallest load so far (ties to the lowest rank); every rank computes the same assignment from
+    the same list, no communication.  Returned in ascending index order."""
     if not (0 <= rank < world):
         raise ValueError("rank out of range")
-    return list(range(rank, n_cases, world))
+    if weights is None:
+        return list(range(rank, n_cases, world))
+    if len(weights) != n_cases:
+        raise ValueError(f"{len(weights)} weights for {n_cases} cases")
+    load = [0.0] * world
+    mine = []
+    for i in sorted(range(n_cases), key=lambda j: (-float(weights[j]), j)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += float(weights[i])
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
 
 
 def shard_tiles(n_tiles: int, rank: int, world: int) -> List[int]:
@@ -73,20 +98,21 @@ def gather_label_maps(seg, group=None):
 
 
 def predict_cases_sharded(models, cases, rank: int, world: int, patch_size=(128, 128, 128), step_size=0.5,
-                          do_mirroring=True, mirror_axes=(0, 1, 2), nonlin="sigmoid", region_order=(1, 2, 3)):
+                          do_mirroring=True, mirror_axes=(0, 1, 2), nonlin="sigmoid", region_order=(1, 2, 3), weights=None):
     """Partitioning A (BASELINE.json configs[3]): this rank's share of a batch of cases, no data-path collective.
 
     ``models`` is a list of ensemble members, each a list of fold networks (the reference runs model 1 then model 2
     with five folds each, driver :263-264); ``cases[i]`` is ``(data, props)`` as ``preprocess_case`` returns it, or a
     callable producing that (so a rank only materialises its own cases).  Per case: fold-mean probabilities per
     member (driver :128), region labels pasted at the crop box (:144-156), label-round ensemble of two members
-    (:305).  Returns ``{case index: uint8 label volume on the device}`` for the cases with ``index % world == rank``.
+    (:305).  Returns ``{case index: uint8 label volume on the device}`` for this rank's cases (``shard_cases``: round-robin,
+    or longest-first by ``weights`` = tile counts when given).
     """
     from . import ops, predictor
     if len(models) not in (1, 2):
         raise ValueError("the reference ensembles one or two members (label-round ensemble is pairwise)")
     out = {}
-    for i in shard_cases(len(cases), rank, world):
+    for i in shard_cases(len(cases), rank, world, weights):
         data, props = cases[i]() if callable(cases[i]) else cases[i]
         lo = [b[0] for b in props["crop_bbox"]]
         segs = []

@@ -67,6 +67,21 @@ def check_spacing(plans: Optional[Dict], spacing_zyx: Optional[Sequence[float]],
             f"{tuple(int(v) for v in new_shape)}; resampling is not implemented (BraTS inputs are 1 mm isotropic)")
 
 
+def nonzero_crop_shape(raw: np.ndarray) -> Tuple[int, int, int]:
+    """Shape of the nonzero crop of ``raw`` [C, Z, Y, X], on the host, without the device pass: the bounding box of
+    ``crop_to_nonzero`` is that of the plain nonzero mask (filled holes are interior, they never move a face).  Used to
+    cost a case (``parallel.tiles_of_shape``) before deciding which rank preprocesses it."""
+    nz = np.any(np.asarray(raw) != 0, axis=0)
+    if not nz.any():
+        return tuple(int(v) for v in nz.shape)
+    out = []
+    for ax in range(3):
+        proj = np.any(nz, axis=tuple(a for a in range(3) if a != ax))
+        idx = np.flatnonzero(proj)
+        out.append(int(idx[-1] - idx[0] + 1))
+    return tuple(out)
+
+
 def preprocess_case(raw: np.ndarray, device="cuda", plans: Optional[Dict] = None,
                     spacing_zyx: Optional[Sequence[float]] = None) -> Tuple["object", Dict]:
     """raw [C,Z,Y,X] (any real dtype) -> (CUDA fp32 [C,Zc,Yc,Xc] normalised, properties dict with

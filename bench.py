@@ -15,8 +15,8 @@ crop -> z-score -> predict -> labels -> D2H) and a `reference_setting` block: th
                     [--no-cpu-baseline] [--no-secondary] [--no-reference-setting]
 
 --config 4 = BASELINE.json configs[3]: a batch of 32 synthetic volumes (seeds 1000..1031), config-3
-settings, CASES sharded round-robin over the ranks (SURVEY.md 8e partitioning A, no data-path
-collective); one step = the whole batch, so this workload scales strongly.
+settings, CASES dealt longest-first by tile count over the ranks (SURVEY.md 8e partitioning A, no
+data-path collective); one step = the whole batch, so this workload scales strongly.
 
 For N > 1 the driver launches this file under torch.distributed.run; when it is started plainly
 with --gpus N > 1 it starts that launcher itself as a child process BEFORE anything touches the
@@ -385,10 +385,23 @@ def run_config4(ctx, args, dtype):
     wl = WORKLOADS[4]
     n_cases = args.cases or wl["n_cases"]
     nets = build_nets(wl["models"], dtype)
-    mine = parallel.shard_cases(n_cases, ctx.rank, ctx.world)
+    # cost of every case in tiles (host-side bounding box of the raw volume; each rank looks at a round-robin share and the
+    # counts are exchanged - bookkeeping outside the timed region), then longest-first assignment (parallel.shard_cases)
+    raws = {i: synthetic.make_volume(seed=1000 + i) for i in parallel.shard_cases(n_cases, ctx.rank, ctx.world)}
+    weights = [0.0] * n_cases
+    for i, raw in raws.items():
+        weights[i] = float(parallel.tiles_of_shape(preprocessing.nonzero_crop_shape(raw), PATCH, 0.5))
+    if ctx.use_dist:
+        dev = ctx.device if ctx.backend == "nccl" else "cpu"
+        wt = ctx.torch.tensor(weights, dtype=ctx.torch.float64, device=dev)
+        ctx.dist.all_reduce(wt)
+        weights = [float(v) for v in wt.tolist()]
+    mine = parallel.shard_cases(n_cases, ctx.rank, ctx.world, weights)
     cases = [None] * n_cases
     for i in mine:  # every rank generates and preprocesses only its own shard, outside the timed region
-        cases[i] = preprocessing.preprocess_case(synthetic.make_volume(seed=1000 + i), ctx.device)
+        raw = raws.pop(i) if i in raws else synthetic.make_volume(seed=1000 + i)
+        cases[i] = preprocessing.preprocess_case(raw, ctx.device)
+    raws.clear()
     tiles = mirrors = 0
     flops_batch = 0
     from brats_amd import ops
@@ -406,7 +419,7 @@ def run_config4(ctx, args, dtype):
         flops_batch, tiles = float(t[0].item()), int(t[1].item())
 
     def step():
-        return parallel.predict_cases_sharded([[n] for n in nets], cases, ctx.rank, ctx.world, PATCH, 0.5, True)
+        return parallel.predict_cases_sharded([[n] for n in nets], cases, ctx.rank, ctx.world, PATCH, 0.5, True, weights=weights)
 
     elapsed, prof, segs = timed_region(ctx, step, args.steps, args.warmup, nets)
     hist = None
@@ -416,7 +429,7 @@ def run_config4(ctx, args, dtype):
     return dict(value=n_cases * args.steps / elapsed, elapsed=elapsed, scaling="strong", dtype=dtype,
                 config={"workload": wl["name"], "patch": list(PATCH), "cases": n_cases, "cases_per_rank": len(mine),
                         "tiles_in_batch": tiles, "mirrors": 8, "models": [m[0] for m in wl["models"]],
-                        "sharding": "cases round-robin over ranks, no data-path collective",
+                        "sharding": "cases longest-first (tile count) onto the least loaded rank, no data-path collective",
                         "tflop_per_batch": round(flops_batch / 1e12, 2)},
                 sustained=flops_batch * args.steps / elapsed / 1e12 / ctx.world,
                 roofline=roofline_of(prof, dtype, traffic_ok=False), kernels=kernel_table(prof), label_histogram=hist)

@@ -85,6 +85,40 @@ def test_two_rank_gloo_tile_sharding(tmp_path):
     assert all((tmp_path / f"ok_{r}.npy").exists() for r in range(2))
 
 
+def test_longest_first_case_assignment(amd):
+    """real crops run from 2 to 12 tiles; round-robin by index can leave one rank with
+    all the large cases.  shard_cases(..., weights) = longest-processing-time-first: a partition, deterministic, never worse
+    than round-robin on these lists and within 4/3 of the lower bound max(mean load, largest case)."""
+    par = amd.parallel
+    rs = np.random.RandomState(5)
+    for world in (2, 3, 8):
+        for trial in range(20):
+            n = int(rs.randint(world, 40))
+            w = [float(v) for v in rs.choice([2, 4, 6, 8, 12, 18], size=n)]
+            parts = [par.shard_cases(n, r, world, w) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))                       # disjoint and complete
+            assert parts == [par.shard_cases(n, r, world, list(w)) for r in range(world)]  # same answer on every rank
+            span = max(sum(w[i] for i in p) for p in parts)
+            rr = max(sum(w[i] for i in par.shard_cases(n, r, world)) for r in range(world))
+            assert span <= rr + 1e-9
+            assert span <= 4.0 / 3.0 * max(sum(w) / world, max(w)) + 1e-9
+    # the adversarial list for round-robin at world 2: large cases on even indices
+    w = [12, 2, 12, 2, 12, 2, 12, 2]
+    assert max(sum(w[i] for i in par.shard_cases(8, r, 2, w)) for r in range(2)) == 28
+    assert max(sum(w[i] for i in par.shard_cases(8, r, 2)) for r in range(2)) == 48
+    # equal costs (the synthetic batch: 8 tiles each): as balanced as round-robin
+    assert sorted(len(par.shard_cases(32, r, 8, [8.0] * 32)) for r in range(8)) == [4] * 8
+    with pytest.raises(ValueError):
+        par.shard_cases(3, 0, 2, [1.0, 2.0])
+    # tile count of a crop = product of the step-table lengths (SURVEY.md appendix A)
+    assert par.tiles_of_shape((140, 171, 137)) == 8 and par.tiles_of_shape((155, 240, 240)) == 18
+    assert par.tiles_of_shape((155, 208, 177)) == 12 and par.tiles_of_shape((98, 134, 117)) == 2
+    raw = np.zeros((4, 20, 30, 40), np.float32)
+    raw[1, 3:9, 5:25, 7:8] = 1.0
+    raw[0, 4, 6, 30] = 2.0
+    assert amd.preprocessing.nonzero_crop_shape(raw) == (6, 20, 24)
+
+
 def test_shard_helpers(amd):
     assert amd.parallel.shard_cases(32, 3, 8) == [3, 11, 19, 27]
     assert sorted(sum((amd.parallel.shard_cases(10, r, 4) for r in range(4)), [])) == list(range(10))

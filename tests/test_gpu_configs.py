@@ -124,3 +124,26 @@ def test_config5_segmentation_then_knowledge_base_retrieval(amd, gpu, tmp_path):
     top = big.topk(store._query_vector("Why is there edema around the tumor?"), 2)
     assert [i - 50000 for i, _ in top] == [[d["source"] for d in fx["docs"]].index(s) for s in fx["expected"][1]["top"]]
     net.close()
+
+
+def test_bench_config4_under_the_launcher(gpu):
+    """The exact command shape the driver's SCALE run uses (python -m torch.distributed.run ... bench.py --gpus N --config 4),
+    at N = 1 with two cases and one step: a real `nccl` process group, the tile-count exchange, longest-first sharding and
+    the one-line JSON contract.  Runs as a child process (the parent keeps its own HIP context; two processes on the card)."""
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "4", "--cases", "2", "--steps", "1",
+           "--warmup", "0"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["steps"] == 1 and out["scaling"] == "strong" and out["dtype"] == "f16"
+    assert out["config"]["cases"] == 2 and out["config"]["cases_per_rank"] == 2 and out["config"]["tiles_in_batch"] == 16
+    assert out["value"] > 0 and out["roofline"]["kernel"].startswith("conv3_f16")
+    assert sum(out["label_histogram"]) == 155 * 240 * 240
