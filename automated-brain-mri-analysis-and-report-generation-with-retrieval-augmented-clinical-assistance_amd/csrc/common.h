@@ -102,6 +102,22 @@ __device__ __forceinline__ double quantise_partial(double v, int k, long voxels)
     return ldexp(rint(ldexp(v, -e)), e);
 }
 
+// fp16 activation layout (round 3): channel-blocked NDHWC, [N][C / 8][D][H][W][8] ("B8", oneDNN's nCdhw8c).  A voxel's eight
+// channels of one block are the 16 bytes ONE lane feeds the matrix cores (v_mfma_f32_32x32x16_f16 B operand: lane = voxel,
+// channels 8 (lane >> 5) .. + 7), and x-consecutive voxels of a block are contiguous, so
+//   * an LDS-DMA piece (64 lanes x 16 B) of a brick reads rows of 160+ contiguous bytes instead of 64 lines that each give
+//     16 of their 128 bytes: tools/dma_probe.hip measures 84-128 cycles per instruction for such rows against 256 for the
+//     16- or 32-byte pieces of plain NDHWC, and 5-8 times the bytes per clock once the lines come from beyond the L2
+//     (profiles/r03_dma_probe.txt);
+//   * the 16-channel chunks of a convolution no longer share 128-B lines: with plain NDHWC a chunk fetched a quarter of
+//     each line and the next chunk found the line evicted (2.4-6.8 x the algorithmic bytes through the fabric, round 2);
+//   * epilogues store whole lines (8 voxels x 16 B per block row) without gathering 64 couts of a voxel first.
+// The fp32 path keeps plain NDHWC (16 B = 4 channels there; its kernels stage 8- and 16-channel chunks of whole lines).
+// Element (n, c, v) of a tensor with C channels and V voxels per sample:
+__host__ __device__ __forceinline__ size_t b8_index(int64_t n, int c, int64_t v, int C, int64_t V) {
+    return (size_t)(((n * (C >> 3) + (c >> 3)) * V + v) * 8 + (c & 7));
+}
+
 // Compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N).  Indices are constant EXPRESSIONS inside the body
 // (inline-asm immediates, register-array subscripts), whatever the optimiser decides about a "#pragma unroll" loop.
 template <int I, int N, class F>

@@ -1,4 +1,6 @@
-// 3x3x3 convolution, NDHWC fp16 storage / fp32 accumulate, on v_mfma_f32_32x32x16_f16 (gfx950).
+// 3x3x3 convolution, fp16 storage / fp32 accumulate, on v_mfma_f32_32x32x16_f16 (gfx950).
+// Activations are channel-blocked NDHWC since round 3: [N][C / 8][D][H][W][8] (common.h, "fp16 activation layout") - a
+// lane's 16-byte MFMA fragment is one 8-channel block of one voxel, x-consecutive voxels of a block are contiguous.
 //
 // BASELINE.json configs[2] ("fp16") path of the same op as conv3d.hip (reference
 // model_architecture/generic_UNet.py:56,69 run under autocast upstream).  Same GEMM mapping as the
@@ -152,7 +154,9 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
             const int v = (wave * MF + mf) * 32 + l31;
             const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
             const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
-            half_t *orow = p.out + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + 4 * half;
+            // couts co_blk + 32 nf + 8 g + 4 half .. + 3: block (co_blk >> 3) + 4 nf + g of the blocked output, position 4 half
+            const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
+            half_t *orow = p.out + (((size_t)n * (p.Cout >> 3) + (co_blk >> 3)) * Vo + ((size_t)oz * p.Ho + oy) * p.Wo + ox) * 8 + 4 * half;
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
@@ -173,7 +177,7 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
                         val[k] = (half_t)m0;
                         val[k + 1] = (half_t)m1;
                     }
-                    if (ok) store_f16x4<SC1>(orow + nf * 32 + 8 * g, val);
+                    if (ok) store_f16x4<SC1>(orow + (size_t)(nf * 4 + g) * Vo * 8, val);
                 }
         }
         return;
@@ -188,7 +192,8 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
         const int v = (wave * MF + mf) * 32 + l31;
         const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
         const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
-        half_t *orow = p.out + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + 4 * half;
+        const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
+        half_t *orow = p.out + (((size_t)n * (p.Cout >> 3) + (co_blk >> 3)) * Vo + ((size_t)oz * p.Ho + oy) * p.Wo + ox) * 8 + 4 * half;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
@@ -201,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
                     val[k] = (half_t)x;
                     if (ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
                 }
-                if (ok) store_f16x4<SC1>(orow + nf * 32 + 8 * g, val);
+                if (ok) store_f16x4<SC1>(orow + (size_t)(nf * 4 + g) * Vo * 8, val);
             }
         }
     }
@@ -274,7 +279,8 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
         const half_t *src; int Csrc, coff;
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
-        src += (size_t)n * p.Di * p.Hi * p.Wi * Csrc + coff;
+        const size_t Vi = (size_t)p.Di * p.Hi * p.Wi;
+        src += ((size_t)n * (Csrc >> 3) + (coff >> 3)) * Vi * 8;  // block coff / 8 of sample n; piece q = the next block
         constexpr int U = 4;
         for (int i0 = tid; i0 < npieces; i0 += 256 * U) {
             f32x4 v[U];
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
                                 ((unsigned)ix < (unsigned)p.Wi);
                 dst[u] = (i < npieces) ? q * p.plane_bytes + bv * 16 : -1;
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (ok) val = *(const f32x4 *)(src + ((size_t)(iz * p.Hi + iy) * p.Wi + ix) * Csrc + q * 8);
+                if (ok) val = *(const f32x4 *)(src + ((size_t)q * Vi + (size_t)(iz * p.Hi + iy) * p.Wi + ix) * 8);
                 v[u] = val;
             }
 #pragma unroll
@@ -351,7 +357,9 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
 }
 
 // out = fp16(act(sum_s partial[s])), slices added in slice order (slice 0 carries the bias)
-__global__ __launch_bounds__(256) void splitk_finish_f16_kernel(const float *partial, int S, long total4, int act, float slope, half_t *out) {
+// (partial sums are plain NDHWC fp32, 4 consecutive couts per thread; the fp16 output is channel-blocked, common.h)
+__global__ __launch_bounds__(256) void splitk_finish_f16_kernel(const float *partial, int S, long total4, int act, float slope, half_t *out,
+                                                                int C, long V) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     f32x4 v = *(const f32x4 *)(partial + i * 4);
@@ -363,7 +371,9 @@ __global__ __launch_bounds__(256) void splitk_finish_f16_kernel(const float *par
     f16x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = (half_t)fmaxf(v[k], v[k] * sl);
-    *(f16x4 *)(out + i * 4) = o;
+    const long e = i * 4, nv = e / C;
+    const int c = (int)(e - nv * C);
+    *(f16x4 *)(out + b8_index(nv / V, c, nv % V, C, V)) = o;
 }
 
 // ------------------------------------------------------------------ pipelined persistent kernel (stride 1)
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         const int x = v & TXm, y = (v >> p.lx) & TYm, z = v >> (p.lx + p.ly);
         a_base[mf] = half * p.plane_bytes + ((z * STRIDE * IY + y * STRIDE) * IX + x * STRIDE) * 16;
     }
-    const int qoff = (tid & 1) * 8;
+    const unsigned qoff = (unsigned)(tid & 1) * (unsigned)((long)p.Di * p.Hi * p.Wi * 16);  // bytes to the lane's 8-channel block (host check: < 2^31)
 
     struct TileCoord { int n, oz0, oy0, ox0; };
     auto decode = [&](int t) {
@@ -470,10 +480,13 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         }
         // wave-uniform descriptor based at the brick origin voxel (may lie one voxel outside the tensor: only pieces
         // inside the volume are addressed through it)
-        const long base_vox = (((long)tc.n * p.Di + (STRIDE * tc.oz0 - 1)) * p.Hi + (STRIDE * tc.oy0 - 1)) * p.Wi + (STRIDE * tc.ox0 - 1);
-        const half_t *sbase = src + base_vox * Csrc + coff;
+        // (blocked tensors: block coff / 8 of sample n, brick origin voxel within the sample; the lane's 8-channel half is the
+        //  next block, Vi voxels further)
+        const long Vi = (long)p.Di * p.Hi * p.Wi;
+        const long base_vox = ((long)(STRIDE * tc.oz0 - 1) * p.Hi + (STRIDE * tc.oy0 - 1)) * p.Wi + (STRIDE * tc.ox0 - 1);
+        const half_t *sbase = src + (((long)tc.n * (Csrc >> 3) + (coff >> 3)) * Vi + base_vox) * 8;
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sbase, 0, 0x7fffffff, 0x00020000);
-        const unsigned off = __umul24((unsigned)pk & 0xffffffu, (unsigned)(Csrc * 2)) + qoff * 2;
+        const unsigned off = (((unsigned)pk & 0xffffffu) << 4) + qoff;
         const unsigned voff = inside ? off : 0xffffffffu;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
@@ -678,13 +691,14 @@ struct DmaGeomH {
     static constexpr int IX = 10, IY = 10, IZ = 10, BV = IX * IY * IZ;
     static constexpr int PLANE_SLOTS = 1024, PLANE_BYTES = PLANE_SLOTS * 16, BUF_BYTES = 2 * PLANE_BYTES;
 #ifndef MI355_H16_INTERLEAVED
-#define MI355_H16_INTERLEAVED 1
+#define MI355_H16_INTERLEAVED 0
 #endif
-    // Brick layout in LDS.  Interleaved [voxel][8-channel half][16 B] (round 2, second version): two adjacent lanes of a DMA
-    // fetch the 32 contiguous bytes of one voxel, so an instruction touches 32 lines instead of the 64 of the planar layout
-    // [half][voxel][16 B] - and the issue of the 64-line DMAs was this kernel's largest loss.  The price: the fragment reads
-    // (lane = voxel, stride 32 B) are 2-way bank conflicts, 32 instead of 16 cycles per wave-level ds_read_b128
-    // (tools/lds_probe.hip) - of an LDS that this kernel uses to a quarter (256 B/clk on gfx950).
+    // Brick layout in LDS.  Round 3: planar [8-channel half][voxel][16 B] - with channel-blocked activations (common.h) the 64
+    // lanes of a piece fetch 64 consecutive brick voxels of ONE block, i.e. rows of 10 x 16 contiguous bytes, and the
+    // fragment reads (lane = voxel, stride 16 B) are conflict-free.  (Round 2, plain NDHWC: interleaved [voxel][half][16 B] so
+    // that two adjacent lanes fetched the 32 contiguous bytes of a voxel - 32 lines per instruction instead of 64 - at the
+    // price of 2-way bank conflicts on every fragment read; MI355_H16_INTERLEAVED=1 still builds it: adjacent lanes then
+    // fetch from two blocks.)
     static constexpr bool INTERLEAVED = MI355_H16_INTERLEAVED != 0;
     static constexpr int VOX_BYTES = INTERLEAVED ? 32 : 16;
     static constexpr int D = 9;    // weight ring depth in taps (divides 27: the ring phase is the same in every chunk)
@@ -774,20 +788,23 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
         const int face = (bz == 0) | ((bz == G::IZ - 1) << 1) | ((by == 0) << 2) | ((by == IY - 1) << 3) | ((bx == 0) << 4) | ((bx == IX - 1) << 5);
         dma_pk[k] = bv < G::BV ? (unsigned)(((bz * p.Hi + by) * p.Wi + bx) | (face << 24)) : (64u << 24);
     }
-    const unsigned lane_half16 = (lane & 1) * 16;
+    const unsigned lane_half16 = (lane & 1) * 16;  // (interleaved brick: the lane's half within a voxel's 32 B of LDS / of the tables)
+    const unsigned lane_half1 = (unsigned)(lane & 1) * (unsigned)((long)p.Di * p.Hi * p.Wi * 16);  // ... and its block in global memory
     auto dma = [&](const TileCoord &tc, int faces, int ch, auto k_c, char *buf) {
         constexpr int k = decltype(k_c)::value;
         const int cglob = ch * 16;
         const half_t *src; int Csrc, coff;
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
-        // wave-uniform part (SALU): the brick origin voxel, which may lie one voxel outside the tensor
-        src += ((((long)tc.n * p.Di + (tc.oz0 - 1)) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1)) * (long)Csrc + coff;
+        // wave-uniform part (SALU): block coff / 8 (+ the piece's half in the planar layout) of sample n, at the brick origin
+        // voxel, which may lie one voxel outside the tensor
+        const long Vi = (long)p.Di * p.Hi * p.Wi;
+        src += (((long)tc.n * (Csrc >> 3) + (coff >> 3) + (G::INTERLEAVED ? 0 : (k >> 2))) * Vi + ((long)(tc.oz0 - 1) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1)) * 8;
         unsigned pk = dma_pk[G::INTERLEAVED ? k : (k & 3)];
         asm volatile("" : "+v"(pk));
         bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
-        unsigned off = __umul24(pk & 0xffffffu, (unsigned)(Csrc * 2));  // bytes (< 2^32: host check)
-        if constexpr (G::INTERLEAVED) off += lane_half16;                 // odd lanes: channels 8..15 of the same voxel
+        unsigned off = (pk & 0xffffffu) << 4;  // bytes: 16 per voxel of a block (< 2^32: host check)
+        if constexpr (G::INTERLEAVED) off += lane_half1;                  // odd lanes: the next block (channels 8..15) of the same voxel
         const char *gin = (const char *)src + off;
         asm volatile("" : "+v"(gin));  // (computed for every lane: left to itself the compiler branches around it, and a basic-block
                                        //  boundary between the MFMAs of a tap makes it wait for every outstanding LDS read there)
@@ -797,10 +814,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
             char *dst = buf + (wave + 4 * k) * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         } else {
-            // plane 1 = channels 8..15: the instruction's immediate is added to the global AND the LDS address
-            char *dst = buf + (k >> 2) * G::PLANE_BYTES + (wave + 4 * (k & 3)) * 1024 - (k >> 2) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst,
-                                             16, (k >> 2) * 16, 0);
+            char *dst = buf + (k >> 2) * G::PLANE_BYTES + (wave + 4 * (k & 3)) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
 
@@ -1064,15 +1079,18 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                     }
                 }
             });
-            // rows 8 j .. 8 j + 7 of the image are the x-row (z = 2 wave + (j >> 3), y = j & 7) of the tile: 8 voxels x 128 B
-            unsigned rd = img + (lane >> 3) * G::EPI_PITCH + (lane & 7) * 16;
+            // rows 8 j .. 8 j + 7 of the image are the x-row (z = 2 wave + (j >> 3), y = j & 7) of the tile: 8 voxels x 8 cout blocks.
+            // Blocked output: lane -> (block lane >> 3, voxel x = lane & 7): 8 lanes write the 128 contiguous bytes of a block's
+            // x-row, a store instruction eight whole lines
+            unsigned rd = img + (lane & 7) * G::EPI_PITCH + (lane >> 3) * 16;
             asm volatile("" : "+v"(rd));
-            const unsigned lane_off = (unsigned)(lane >> 3) * p.Cout * 2 + (lane & 7) * 16;
-            half_t *obase = p.out + ((((size_t)cur.n * p.Do + cur.oz0 + 2 * wave) * p.Ho + cur.oy0) * p.Wo + cur.ox0) * p.Cout + co_blk;
+            const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
+            const unsigned lane_off = (unsigned)(((size_t)(lane >> 3) * Vo + (lane & 7)) * 16);  // (< 2^32: host check)
+            half_t *obase = p.out + (((size_t)cur.n * (p.Cout >> 3) + (co_blk >> 3)) * Vo + ((size_t)(cur.oz0 + 2 * wave) * p.Ho + cur.oy0) * p.Wo + cur.ox0) * 8;
             static_for<0, 16>([&](auto j_c) {
                 constexpr int j = decltype(j_c)::value;
                 const f32x4 v = *(const __attribute__((address_space(3))) f32x4 *)(rd + j * 8 * G::EPI_PITCH);
-                const char *row = (const char *)(obase + ((size_t)(j >> 3) * p.Ho + (j & 7)) * p.Wo * p.Cout);
+                const char *row = (const char *)(obase + ((size_t)(j >> 3) * p.Ho + (j & 7)) * p.Wo * 8);
                 const unsigned lo = lane_off;
 #ifndef MI355_H16_SC1
 #define MI355_H16_SC1 1
@@ -1264,7 +1282,8 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
                 else { if (kernel_name) *kernel_name = "conv3_f16_mfma_kernel<2, 1, 2> split-K"; rc = launch_h(conv3_f16_mfma_kernel<2, 1, 2>, b, grid, lds_bytes, s, &attr_sk[3]); }
                 if (rc != MI355_OK) return rc;
                 const long total4 = out_elems / 4;
-                hipLaunchKernelGGL(splitk_finish_f16_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial, S, total4, c.act, c.slope, c.out);
+                hipLaunchKernelGGL(splitk_finish_f16_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial, S, total4, c.act, c.slope, c.out,
+                                   w.cout, (long)a.Do * a.Ho * a.Wo);
                 MI355_HIP(hipGetLastError());
                 return MI355_OK;
             }
@@ -1280,11 +1299,10 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         b.IX = b.IY = b.IZ = 10;
         b.div_tiles_per_n = make_fastdiv(b.tiles_x * b.tiles_y * b.tiles_z);
         const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
-        const long cmax = c.C0 > c.C1 ? c.C0 : c.C1;
         typedef DmaGeomH<2> GA;
         const size_t tab_bytes = c.in_scale ? (size_t)c.N * c.C0 * 4 : 0;  // fused input norm: fp16 scale + shift tables in LDS
         if (dmak && tiles * gy >= 512 && tiles < (1l << 30) && b.Do % 8 == 0 && b.Ho % 8 == 0 && b.Wo % 8 == 0 &&
-            (long)10 * c.Hi * c.Wi < (1l << 24) && (long)10 * c.Hi * c.Wi * cmax * 2 < (1l << 32) &&
+            (long)10 * c.Hi * c.Wi < (1l << 24) && ((long)10 * c.Hi * c.Wi + 8l * c.Di * c.Hi * c.Wi) * 16 < (1l << 32) &&
             (!c.in_scale || (c.C1 == 0 && tab_bytes <= (size_t)GA::TAB_MAX_BYTES))) {
             void *zeros = nullptr;  // the zero page out-of-volume DMA pieces read
             MI355_TRY(device_scratch(SCR_ZEROS, 256, &zeros, true));
@@ -1318,7 +1336,8 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         }
         MI355_REQUIRE(tiles < (1l << 30), "conv grid too large");
         MI355_REQUIRE(a.IX * a.IY * a.IZ <= (MF == 4 ? 11 : 8) * 128, "conv brick exceeds the staging slots");
-        MI355_REQUIRE((long)a.IZ * c.Hi * c.Wi < (1l << 24), "volume slab too large for the packed staging offsets");
+        MI355_REQUIRE((long)a.IZ * c.Hi * c.Wi < (1l << 24) && ((long)a.IZ * c.Hi * c.Wi + (long)c.Di * c.Hi * c.Wi) * 16 < (1l << 31),
+                      "volume too large for the 32-bit staging offsets");
         a.total_tiles = (int)tiles;
         const size_t lds_bytes = (size_t)4 * a.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float);
         MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
@@ -1360,7 +1379,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
         const size_t lds_bytes = (size_t)4 * b.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float);
         if (s2pipe && tiles * gy >= 768 && tiles < (1l << 30) && b.IX * b.IY * b.IZ <= 13 * 128 && lds_bytes <= 160 * 1024 &&
-            (long)b.IZ * c.Hi * c.Wi < (1l << 24) && !c.in_scale) {
+            (long)b.IZ * c.Hi * c.Wi < (1l << 24) && ((long)b.IZ * c.Hi * c.Wi + (long)c.Di * c.Hi * c.Wi) * 16 < (1l << 31) && !c.in_scale) {
             b.total_tiles = (int)tiles;
             int gx = 256 / gy;   // one workgroup per CU: the double-buffered brick takes about 100 KB of LDS
             gx = gx < 8 ? 8 : (gx / 8) * 8;

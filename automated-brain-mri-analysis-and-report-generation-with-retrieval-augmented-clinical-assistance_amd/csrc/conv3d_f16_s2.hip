@@ -1,4 +1,4 @@
-// Stride-2 3x3x3 convolution, NDHWC fp16 storage / fp32 accumulate (round 3): the encoder's down-sampling convs
+// Stride-2 3x3x3 convolution, channel-blocked fp16 storage ([N][C / 8][D][H][W][8], common.h) / fp32 accumulate (round 3): the encoder's down-sampling convs
 // (reference model_architecture/generic_UNet.py:285-288,314-315, `first_stride` of StackedConvLayers :128-143) with
 // Cout % 128 == 0 on volumes that are whole 4 x 4 x 8 output tiles.
 //
@@ -20,7 +20,7 @@
 //     hand-counted s_waitcnt vmcnt (loads return in order; see conv3_f16_dma_kernel for why the compiler cannot do it);
 //   * epilogue: bias (the accumulators are initialised with it), LeakyReLU, fp16, transposed through a wave-private LDS
 //     image (row = voxel, 80-B pitch: the 8-B writes of 16 consecutive voxels fall on 16 different bank pairs) into stores
-//     of 16 voxels x 64 B (the wave's 32 couts of a voxel are half a 128-B line; the sibling wave writes the other half);
+//     of 4 cout blocks x 2 x-rows x 8 voxels: whole 128-B lines of the channel-blocked output (common.h);
 //     sum x and sum x^2 per cout for Instance/GroupNorm as in the other kernels (quantised partials, common.h).
 // The stride-2 convs read one input tensor (no virtual concat) and never carry the fused head.
 #include "kernels.h"
@@ -130,12 +130,14 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
         const int d = wave + 4 * k;  // (wave-uniform: scalar arithmetic)
         // wave-uniform part: the brick origin voxel (may lie one voxel outside the tensor), this chunk's 16 channels, and
         // the 8-channel half of the piece's plane
-        const half_t *src = p.in + ((((long)tc.n * p.Di + (2 * tc.oz0 - 1)) * p.Hi + (2 * tc.oy0 - 1)) * p.Wi + (2 * tc.ox0 - 1)) * (long)p.C +
-                            ch * 16 + (d >= G::PLANE_BLOCKS ? 8 : 0);
+        // (channel-blocked input, common.h: block 2 ch + plane of sample n; 16 B per voxel of a block)
+        const long Vi = (long)p.Di * p.Hi * p.Wi;
+        const half_t *src = p.in + (((long)tc.n * (p.C >> 3) + 2 * ch + (d >= G::PLANE_BLOCKS ? 1 : 0)) * Vi +
+                                    ((long)(2 * tc.oz0 - 1) * p.Hi + (2 * tc.oy0 - 1)) * p.Wi + (2 * tc.ox0 - 1)) * 8;
         unsigned pk = dma_pk[k];
         asm volatile("" : "+v"(pk));
         const bool inside = (pk & ((unsigned)(faces | 8) << 24)) == 0;
-        const unsigned off = __umul24(pk & 0xffffffu, (unsigned)(p.C * 2));  // bytes (< 2^32: host check)
+        const unsigned off = (pk & 0xffffffu) << 4;  // bytes (< 2^32: host check)
         const char *gin = (const char *)src + off;
         asm volatile("" : "+v"(gin));  // (computed for every lane: a branch around it is a basic-block boundary between the MFMAs)
         const char *g = inside ? gin : (const char *)p.zeros;
@@ -287,16 +289,18 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
                     }
                 }
             }
-            // image rows 16 j .. 16 j + 15 = output voxels (z = j >> 1, y = 2 (j & 1) + (lane >> 5), x = (lane >> 2) & 7); a lane moves
-            // 16 B: four lanes cover the wave's 64 B of a voxel
-            unsigned rd = img + (lane >> 2) * G::EPI_PITCH + (lane & 3) * 16;
+            // image rows 16 j .. 16 j + 15 = output voxels (z = j >> 1, y = 2 (j & 1) + yy, x), yy = 0, 1.  Blocked output (common.h):
+            // lane -> (cout block lane >> 4 of the wave's four, yy = (lane >> 3) & 1, x = lane & 7): eight lanes write the 128
+            // contiguous bytes of a block's x-row
+            unsigned rd = img + (lane & 15) * G::EPI_PITCH + (lane >> 4) * 16;
             asm volatile("" : "+v"(rd));
-            const unsigned lane_off = (unsigned)(((lane >> 5) * p.Wo + ((lane >> 2) & 7)) * p.Cout * 2 + (lane & 3) * 16);
-            half_t *obase = p.out + ((((size_t)cur.n * p.Do + cur.oz0) * p.Ho + cur.oy0) * p.Wo + cur.ox0) * p.Cout + co_blk + wave * 32;
+            const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
+            const unsigned lane_off = (unsigned)(((size_t)(lane >> 4) * Vo + ((lane >> 3) & 1) * p.Wo + (lane & 7)) * 16);  // (< 2^32: host check)
+            half_t *obase = p.out + (((size_t)cur.n * (p.Cout >> 3) + ((co_blk + wave * 32) >> 3)) * Vo + ((size_t)cur.oz0 * p.Ho + cur.oy0) * p.Wo + cur.ox0) * 8;
             static_for<0, 8>([&](auto j_c) {
                 constexpr int j = decltype(j_c)::value;
                 const f32x4 v = *(const __attribute__((address_space(3))) f32x4 *)(rd + j * 16 * G::EPI_PITCH);
-                const char *rowp = (const char *)(obase + ((size_t)(j >> 1) * p.Ho + 2 * (j & 1)) * p.Wo * p.Cout);
+                const char *rowp = (const char *)(obase + ((size_t)(j >> 1) * p.Ho + 2 * (j & 1)) * p.Wo * 8);
                 const unsigned lo2 = lane_off;
                 // sc1: nothing on this XCD reads the output again; kept in its L2 the lines would evict brick lines
                 asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(lo2), "v"(v), "s"(rowp) : "memory");
@@ -331,7 +335,7 @@ int conv3d_f16_s2dma(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, c
     const long tiles = (long)tiles_x * tiles_y * tiles_z * c.N;
     const int gy = w.cout / 128;
     if (tiles * gy < 256 || tiles >= (1l << 30)) return MI355_OK;
-    if ((long)G::IZ * c.Hi * c.Wi >= (1l << 24) || (long)G::IZ * c.Hi * c.Wi * c.C0 * 2 >= (1l << 32)) return MI355_OK;
+    if ((long)G::IZ * c.Hi * c.Wi >= (1l << 24) || (long)G::IZ * c.Hi * c.Wi * 16 >= (1l << 32) || (long)Do * Ho * Wo * 64 >= (1l << 32)) return MI355_OK;
     S2ArgsH a;
     a.in = c.in0; a.wp = w.wp_dev; a.bias = w.bias_dev; a.out = c.out; a.stats = c.stats;
     a.C = c.C0; a.N = c.N; a.Di = c.Di; a.Hi = c.Hi; a.Wi = c.Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cout = w.cout;

@@ -116,13 +116,27 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
             }
         }
         // (same wave wrote the image: the LDS executes a wave's accesses in order, the compiler inserts the wait)
-        char *orow = (char *)p.out + ((((size_t)n * p.D + oz) * p.H + oy) * p.W + ox0) * p.Cout * sizeof(T) + co_blk * sizeof(T);
         const bool row_ok = (oz < p.D) && (oy < p.H);
+        if constexpr (sizeof(T) == 2) {
+            // fp16 tensors are channel-blocked ([N][C / 8][V][8], common.h): the fragment's 32 voxels are one x-row, 512 contiguous
+            // bytes in each of the four 8-cout blocks; a store instruction writes two blocks x 32 voxels
+            const int64_t V = (int64_t)p.D * p.H * p.W;
+            const int64_t vrow = ((int64_t)oz * p.H + oy) * p.W + ox0;
 #pragma unroll
-        for (int j = 0; j < E::STORES; ++j) {
-            const int q = j * 64 + lane, vox = q / E::UNITS, unit = q % E::UNITS;
-            const f32x4 v = *(const f32x4 *)(img + vox * E::PITCH + unit * 16);
-            if (row_ok && ox0 + vox < p.W) *(f32x4 *)(orow + (size_t)vox * p.Cout * sizeof(T) + unit * 16) = v;
+            for (int j = 0; j < E::STORES; ++j) {
+                const int q = j * 64 + lane, unit = q >> 5, vox = q & 31;
+                const f32x4 v = *(const f32x4 *)(img + vox * E::PITCH + unit * 16);
+                _Float16 *dst = (_Float16 *)p.out + (((int64_t)n * (p.Cout >> 3) + (co_blk >> 3) + unit) * V + vrow + vox) * 8;
+                if (row_ok && ox0 + vox < p.W) *(f32x4 *)dst = v;
+            }
+        } else {
+            char *orow = (char *)p.out + ((((size_t)n * p.D + oz) * p.H + oy) * p.W + ox0) * p.Cout * sizeof(T) + co_blk * sizeof(T);
+#pragma unroll
+            for (int j = 0; j < E::STORES; ++j) {
+                const int q = j * 64 + lane, vox = q / E::UNITS, unit = q % E::UNITS;
+                const f32x4 v = *(const f32x4 *)(img + vox * E::PITCH + unit * 16);
+                if (row_ok && ox0 + vox < p.W) *(f32x4 *)(orow + (size_t)vox * p.Cout * sizeof(T) + unit * 16) = v;
+            }
         }
     }
     if (p.stats) {

@@ -4,6 +4,7 @@
 // the masked z-score.  All accesses are 16 B per lane where the layout allows it.
 #include "kernels.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace mi355 {
@@ -88,16 +89,43 @@ __global__ void norm_apply_kernel(T *x, int64_t total4, int64_t VC4, int C4, con
     }
 }
 
+// fp16 tensors are channel-blocked ([N][C / 8][V][8], common.h): one thread = the 8 channels of a voxel in one block,
+// consecutive threads = consecutive voxels; blockIdx.y = (sample, block): scale / shift are wave-uniform.
+__global__ void norm_apply_b8_kernel(_Float16 *x, int64_t V, int C, const float *scale, const float *shift, int act, float slope) {
+    const int64_t nb = blockIdx.y;  // n * (C / 8) + block
+    const int CB = C >> 3;
+    const int64_t n = nb / CB;
+    const int cb = (int)(nb - n * CB);
+    const float *sc = scale + n * C + cb * 8, *sh = shift + n * C + cb * 8;
+    float s8[8], h8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s8[k] = sc[k]; h8[k] = sh[k]; }
+    _Float16 *base = x + nb * V * 8;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+        f16x8 h = *(const f16x8 *)(base + v * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float y = (float)h[k] * s8[k] + h8[k];
+            if (act == ACT_LRELU) y = y > 0.f ? y : y * slope;
+            h[k] = (_Float16)y;
+        }
+        *(f16x8 *)(base + v * 8) = h;
+    }
+}
+
 int norm_apply(void *x, int dtype, int N, int64_t V, int C, const float *scale, const float *shift, int act,
                float slope, hipStream_t s) {
     MI355_REQUIRE(C % 4 == 0, "norm_apply: C=%d", C);
     const int64_t total4 = (int64_t)N * V * C / 4;
     int64_t blocks = (total4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (dtype == MI355_F16)
-        hipLaunchKernelGGL(norm_apply_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, (_Float16 *)x, total4,
-                           V * C / 4, C / 4, (const f32x4 *)scale, (const f32x4 *)shift, act, slope);
-    else
+    if (dtype == MI355_F16) {
+        MI355_REQUIRE(C % 8 == 0 && (int64_t)N * (C / 8) <= 65535, "norm_apply: fp16 tensors are blocked by 8 channels (N = %d, C = %d)", N, C);
+        int64_t bx = (V + 255) / 256;
+        const int64_t cap = std::max<int64_t>(1, 4096 / ((int64_t)N * (C / 8)));
+        if (bx > cap) bx = cap;
+        hipLaunchKernelGGL(norm_apply_b8_kernel, dim3((unsigned)bx, (unsigned)(N * (C / 8))), dim3(256), 0, s, (_Float16 *)x, V, C, scale, shift, act, slope);
+    } else
         hipLaunchKernelGGL(norm_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float *)x, total4,
                            V * C / 4, C / 4, (const f32x4 *)scale, (const f32x4 *)shift, act, slope);
     MI355_HIP(hipGetLastError());
@@ -129,10 +157,14 @@ __global__ void extract_tiles_kernel(const float *vol, int C, int Z, int Y, int 
         const int sx = (td.mirror & 4) ? P2 - 1 - px : px;
         const int gz = td.z0 + sz - padz, gy = td.y0 + sy - pady, gx = td.x0 + sx - padx;
         const bool ok = (unsigned)gz < (unsigned)Z && (unsigned)gy < (unsigned)Y && (unsigned)gx < (unsigned)X;
+        const bool blocked = std::is_same<T, _Float16>::value && (Cpad % 8 == 0);  // (not the stem's NDHW4 input)
         T *dst = x + ((int64_t)b * PV + v) * Cpad;
         const int64_t g = ((int64_t)gz * Y + gy) * X + gx;
-        for (int c = 0; c < Cpad; ++c)
-            dst[c] = (T)((ok && c < C) ? vol[c * ZYX + g] : 0.f);
+        for (int c = 0; c < Cpad; ++c) {
+            const T val = (T)((ok && c < C) ? vol[c * ZYX + g] : 0.f);
+            if (blocked) x[b8_index(b, c, v, Cpad, PV)] = val;
+            else dst[c] = val;
+        }
     }
 }
 
@@ -155,12 +187,15 @@ int extract_tiles(const float *vol, int C, int Z, int Y, int X, int padz, int pa
     return MI355_OK;
 }
 
+// (fp16 with Cpad % 8 == 0, i.e. a network without the stem kernel: channel-blocked output, common.h; the stem's NDHW4 input
+// is a plain 4-channel tensor in both dtypes)
 template <typename T>
 __global__ void nchw_to_ndhwc_kernel(const float *x, int C, int64_t V, int Cpad, T *y, int64_t total) {
+    const bool blocked = std::is_same<T, _Float16>::value && (Cpad % 8 == 0);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = i / V, v = i - n * V;
         for (int c = 0; c < Cpad; ++c)
-            y[i * Cpad + c] = (T)(c < C ? x[(n * C + c) * V + v] : 0.f);
+            y[blocked ? b8_index(n, c, v, Cpad, V) : (size_t)(i * Cpad + c)] = (T)(c < C ? x[(n * C + c) * V + v] : 0.f);
     }
 }
 
@@ -176,10 +211,50 @@ int nchw_to_ndhwc(const float *x, int N, int C, int64_t V, int Cpad, void *y, in
     return MI355_OK;
 }
 
+// plain NDHWC <-> channel-blocked fp16 (common.h): the single-op entry points of the C ABI take and return plain NDHWC
+// tensors (include/mi355_nnunet.h), the kernels work on blocked ones
+__global__ void ndhwc_to_b8_kernel(const _Float16 *x, int C, int64_t V, int64_t total8, _Float16 *y) {
+    const int CB = C >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        // i = (n * CB + cb) * V + v : one 16-B piece of the blocked tensor
+        const int64_t v = i % V, nb = i / V;
+        const int64_t n = nb / CB;
+        const int cb = (int)(nb - n * CB);
+        *(f16x8 *)(y + i * 8) = *(const f16x8 *)(x + (n * V + v) * C + cb * 8);
+    }
+}
+__global__ void b8_to_ndhwc_kernel(const _Float16 *x, int C, int64_t V, int64_t total8, _Float16 *y) {
+    const int CB = C >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = i % V, nb = i / V;
+        const int64_t n = nb / CB;
+        const int cb = (int)(nb - n * CB);
+        *(f16x8 *)(y + (n * V + v) * C + cb * 8) = *(const f16x8 *)(x + i * 8);
+    }
+}
+int ndhwc_to_b8(const _Float16 *x, int N, int C, int64_t V, _Float16 *y, hipStream_t s) {
+    MI355_REQUIRE(C % 8 == 0, "blocked fp16 layout needs C %% 8 == 0 (got %d)", C);
+    const int64_t total8 = (int64_t)N * V * (C / 8);
+    int64_t blocks = (total8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(ndhwc_to_b8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, C, V, total8, y);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+int b8_to_ndhwc(const _Float16 *x, int N, int C, int64_t V, _Float16 *y, hipStream_t s) {
+    MI355_REQUIRE(C % 8 == 0, "blocked fp16 layout needs C %% 8 == 0 (got %d)", C);
+    const int64_t total8 = (int64_t)N * V * (C / 8);
+    int64_t blocks = (total8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(b8_to_ndhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, C, V, total8, y);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
 // ------------------------------------------------------------------ segmentation head
 int head_weights_upload(const float *w_host, const float *b_host, int cin, int ncls, HeadWeights *out) {
     MI355_REQUIRE(ncls >= 1 && ncls <= 8, "head: %d classes unsupported (max 8)", ncls);
-    MI355_REQUIRE(cin % 4 == 0, "head: cin %d not a multiple of 4", cin);
+    MI355_REQUIRE(cin % 8 == 0, "head: cin %d not a multiple of 8", cin);
     HeadWeights h;
     h.cin = cin; h.ncls = ncls;
     MI355_HIP(hipMalloc(&h.w_dev, (size_t)ncls * cin * sizeof(float)));
@@ -207,17 +282,29 @@ constexpr int HEAD_MAX_CLS = 8;
 // per channel with this sample's scale / shift (wave-uniform: scalar loads) - generic_UNet.py:62-72 is one expression,
 // lrelu(instnorm(conv(x))), and this kernel reads every feature exactly once anyway (round 3: removes the norm_apply pass
 // over the widest-resolution tensor of the decoder).
+// `feat` = this sample's feature map, `v` = the voxel, V = voxels per sample.  fp32 tensors are plain NDHWC ([V][C]), fp16
+// tensors channel-blocked ([C / 8][V][8], common.h): either way consecutive lanes (voxels) read consecutive 16-B pieces.
 template <typename T, bool NORM>
-__device__ __forceinline__ void head_dot(const T *feat_vox, const float *__restrict__ w, const float *__restrict__ b,
+__device__ __forceinline__ void head_dot(const T *feat, int64_t v, int64_t V, const float *__restrict__ w, const float *__restrict__ b,
                                          int C, int ncls, float *logit, const float *__restrict__ sc = nullptr,
                                          const float *__restrict__ sh = nullptr, float nslope = 1.0f) {
 #pragma unroll
     for (int k = 0; k < HEAD_MAX_CLS; ++k) logit[k] = (k < ncls) ? b[k] : 0.f;
-    for (int c = 0; c < C; c += 4) {
-        f32x4 f = load4<T>(feat_vox + c);
+    constexpr int CW = std::is_same<T, _Float16>::value ? 8 : 4;  // channels per 16-B piece
+    for (int c = 0; c < C; c += CW) {
+        float f[CW];
+        if constexpr (std::is_same<T, _Float16>::value) {
+            const f16x8 h = *(const f16x8 *)(feat + ((int64_t)(c >> 3) * V + v) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (float)h[j];
+        } else {
+            const f32x4 q = *(const f32x4 *)(feat + v * C + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = q[j];
+        }
         if constexpr (NORM) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < CW; ++j) {
                 const float y = fmaf(f[j], sc[c + j], sh[c + j]);
                 f[j] = fmaxf(y, y * nslope);  // nslope = 1: no activation (max(y, y) = y)
             }
@@ -226,7 +313,10 @@ __device__ __forceinline__ void head_dot(const T *feat_vox, const float *__restr
         for (int k = 0; k < HEAD_MAX_CLS; ++k)
             if (k < ncls) {
                 const float *wk = w + k * C + c;
-                logit[k] = fmaf(f[0], wk[0], fmaf(f[1], wk[1], fmaf(f[2], wk[2], fmaf(f[3], wk[3], logit[k]))));
+                // (same association as round 2: channels c+3, c+2, c+1, c innermost to outermost, 4 at a time)
+#pragma unroll
+                for (int q4 = 0; q4 < CW; q4 += 4)
+                    logit[k] = fmaf(f[q4], wk[q4], fmaf(f[q4 + 1], wk[q4 + 1], fmaf(f[q4 + 2], wk[q4 + 2], fmaf(f[q4 + 3], wk[q4 + 3], logit[k]))));
             }
     }
 }
@@ -237,9 +327,8 @@ __global__ void head_logits_kernel(const T *feat, const float *w, const float *b
     // (blockIdx.y = sample: the per-sample scale / shift rows stay wave-uniform)
     const int64_t n = blockIdx.y;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = n * V + v;
         float lg[HEAD_MAX_CLS];
-        head_dot<T, NORM>(feat + i * C, w, b, C, ncls, lg, NORM ? fn.scale + n * C : nullptr, NORM ? fn.shift + n * C : nullptr, fn.slope);
+        head_dot<T, NORM>(feat + n * V * C, v, V, w, b, C, ncls, lg, NORM ? fn.scale + n * C : nullptr, NORM ? fn.shift + n * C : nullptr, fn.slope);
 #pragma unroll
         for (int k = 0; k < HEAD_MAX_CLS; ++k)
             if (k < ncls) logits[(n * ncls + k) * V + v] = lg[k];
@@ -295,7 +384,7 @@ __global__ void head_aggregate_kernel(const T *feat, const float *w, const float
             const int64_t sv = ((int64_t)sz * P1 + sy) * P2 + sx;
             float lg[HEAD_MAX_CLS];
             // (fn.scale / fn.shift already point at this tile's first sample)
-            head_dot<T, NORM>(feat + ((int64_t)mi * PV + sv) * C, w, b, C, ncls, lg, NORM ? fn.scale + mi * C : nullptr,
+            head_dot<T, NORM>(feat + (int64_t)mi * PV * C, sv, PV, w, b, C, ncls, lg, NORM ? fn.scale + mi * C : nullptr,
                               NORM ? fn.shift + mi * C : nullptr, fn.slope);
             if (nonlin == MI355_NONLIN_SIGMOID) {
 #pragma unroll

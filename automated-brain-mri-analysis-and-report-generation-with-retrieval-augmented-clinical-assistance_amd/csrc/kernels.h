@@ -124,6 +124,9 @@ struct TileDesc {  // one forward sample = one (tile, mirror)
 int extract_tiles(const float *vol, int C, int Z, int Y, int X, int padz, int pady, int padx,
                   const TileDesc *tiles_host, int n_samples, int P0, int P1, int P2, int Cpad, void *x, int dtype,
                   hipStream_t s);
+// plain NDHWC <-> channel-blocked [N][C / 8][V][8] fp16 (common.h)
+int ndhwc_to_b8(const _Float16 *x, int N, int C, int64_t V, _Float16 *y, hipStream_t s);
+int b8_to_ndhwc(const _Float16 *x, int N, int C, int64_t V, _Float16 *y, hipStream_t s);
 // NCDHW -> NDHWC(Cpad) for the plain forward API
 int nchw_to_ndhwc(const float *x, int N, int C, int64_t V, int Cpad, void *y, int dtype, hipStream_t s);
 

@@ -246,12 +246,15 @@ __global__ __launch_bounds__(256) void tconv2_f16_mfma_kernel(const _Float16 *__
     const int pos = (int)blockIdx.y / nblk, nb = (int)blockIdx.y - pos * nblk;
     const int G = Cin >> 4;
     const int m0 = ((int)blockIdx.x * 4 + wave) * (MF * 32);
+    // fp16 tensors are channel-blocked ([N][C / 8][V][8], common.h): voxel v of sample n, block 2 g + half
+    const long Vi = (long)D * H * W;
     const _Float16 *xrow[MF];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         int v = m0 + mf * 32 + l31;
         if (v >= M) v = M - 1;
-        xrow[mf] = in + (size_t)v * Cin + half * 8;
+        const uint32_t n = fdiv(fdiv(fdiv((uint32_t)v, divW), divH), divD);
+        xrow[mf] = in + ((long)n * (Cin >> 3) * Vi + (v - (long)n * Vi) + half * Vi) * 8;
     }
     const _Float16 *wrow = wp + ((size_t)(pos * nblk + nb) * G) * 512 + lane * 8;
     f32x16 acc[MF];
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void tconv2_f16_mfma_kernel(const _Float16 *__
         const f16x8 wf = *(const f16x8 *)(wrow + (size_t)g * 512);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-            const f16x8 xf = *(const f16x8 *)(xrow[mf] + g * 16);
+            const f16x8 xf = *(const f16x8 *)(xrow[mf] + (long)g * Vi * 16);
             acc[mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[mf], 0, 0, 0);
         }
     }
@@ -280,12 +283,14 @@ __global__ __launch_bounds__(256) void tconv2_f16_mfma_kernel(const _Float16 *__
             const int y = (int)q1 - (int)q2 * H;
             const uint32_t n = fdiv(q2, divD);
             const int z = (int)q2 - (int)n * D;
-            _Float16 *o = out + ((((size_t)n * Do + 2 * z + pa) * Ho + 2 * y + pb) * Wo + 2 * x + pc) * Cout + nb * 32 + 4 * half;
+            // couts nb * 32 + 8 g + 4 half .. + 3 = block nb * 4 + g, position 4 half of the blocked output
+            const long Vo = (long)Do * Ho * Wo;
+            _Float16 *o = out + (((long)n * (Cout >> 3) + nb * 4) * Vo + (((long)2 * z + pa) * Ho + 2 * y + pb) * Wo + 2 * x + pc) * 8 + 4 * half;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f16x4 hv = {(_Float16)acc[mf][4 * g], (_Float16)acc[mf][4 * g + 1], (_Float16)acc[mf][4 * g + 2],
                             (_Float16)acc[mf][4 * g + 3]};
-                *(f16x4 *)(o + 8 * g) = hv;
+                *(f16x4 *)(o + (long)g * Vo * 8) = hv;
             }
         }
     }
@@ -325,12 +330,15 @@ __global__ __launch_bounds__(256, 2) void tconv2_f16_mfma_v2_kernel(const _Float
     for (int c0 = 0; c0 < Cin; c0 += 64) {
         const int cp = (Cin - c0 < 64 ? Cin - c0 : 64) >> 3;  // 16-B pieces (8 channels) in this chunk (Cin % 16 == 0)
         if (c0) __syncthreads();
+        // (fp16 tensors are channel-blocked, [N][C / 8][V][8], common.h: consecutive lanes = consecutive voxels of one block)
 #pragma unroll
         for (int k2 = 0; k2 < 4; ++k2) {
-            const int i = k2 * 256 + tid, v = i >> 3, q = i & 7;
+            const int i = k2 * 256 + tid, v = i & 127, q = i >> 7;
             int vg = m0 + v;
             if (vg >= M) vg = M - 1;
-            if (q < cp) *(f32x4_t *)(xs + q * XPLANE + v * 8) = *(const f32x4_t *)(in + (size_t)vg * Cin + c0 + q * 8);
+            const uint32_t ns = fdiv(fdiv(fdiv((uint32_t)vg, divW), divH), divD);
+            const long Vi = (long)D * H * W;
+            if (q < cp) *(f32x4_t *)(xs + q * XPLANE + v * 8) = *(const f32x4_t *)(in + (((long)ns * (Cin >> 3) + (c0 >> 3) + q) * Vi + (vg - (long)ns * Vi)) * 8);
         }
         __syncthreads();
         const int gn = cp >> 1;
@@ -350,7 +358,10 @@ __global__ __launch_bounds__(256, 2) void tconv2_f16_mfma_v2_kernel(const _Float
     _Float16 *mytr = tr[wave];
     const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
     const int pa = wave >> 1, pb = wave & 1;  // parities 2w, 2w+1 = (pa, pb, 0) and (pa, pb, 1)
-    const long padd = (((long)pa * Ho + pb) * Wo) * Cout + nb * 32;  // elements
+    // blocked output ([N][Cout / 8][Vo][8]): a wave's two parities are x-neighbours, so the 32 input voxels of a fragment (one
+    // x-row when W >= 32) become 64 consecutive output voxels = 1 KiB contiguous in each of the four 8-cout blocks
+    const long Vo = (long)Do * Ho * Wo;
+    const long padd = ((long)pa * Ho + pb) * Wo;  // voxels
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf) {
         const int v = m0 + mf * 32 + l31;
@@ -361,7 +372,8 @@ __global__ __launch_bounds__(256, 2) void tconv2_f16_mfma_v2_kernel(const _Float
         const int y = (int)q1 - (int)q2 * H;
         const uint32_t n = fdiv(q2, divD);
         const int z = (int)q2 - (int)n * D;
-        const long vox000 = v < M ? ((((long)n * Do + 2 * z) * Ho + 2 * y) * Wo + 2 * x) * Cout : -1;  // element offset of the row
+        // 16-B piece index of output voxel (2z, 2y, 2x) in cout block nb * 4 of sample n (-1: row past the end)
+        const long vox000 = v < M ? ((long)n * (Cout >> 3) + nb * 4) * Vo + (((long)2 * z) * Ho + 2 * y) * Wo + 2 * x : -1;
         // write: row = voxel l31 (128 B = 2 parities x 32 couts); 16-B piece pp*4 + g4 at physical piece (piece ^ (row & 7))
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
@@ -373,12 +385,12 @@ __global__ __launch_bounds__(256, 2) void tconv2_f16_mfma_v2_kernel(const _Float
             }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int r = it * 8 + (lane >> 3), c = lane & 7;
-            const f32x4_t val = *(const f32x4_t *)(mytr + r * 64 + ((c ^ (r & 7)) << 3));
+            // store `it` = cout block it: lane -> (input voxel r = lane >> 1, x parity = lane & 1)
+            const int r = lane >> 1, pc = lane & 1;
+            const f32x4_t val = *(const f32x4_t *)(mytr + r * 64 + (((pc * 4 + it) ^ (r & 7)) << 3));
             const int lo = __shfl((int)(vox000 & 0xffffffff), r), hi = __shfl((int)(vox000 >> 32), r);
             const long vo = ((long)hi << 32) | (unsigned)lo;
-            // piece c: parity (c >> 2), couts 8 * (c & 3) .. + 7 of this cout block
-            if (vo >= 0) *(f32x4_t *)(out + (vo + padd) + (c >> 2) * Cout + (c & 3) * 8) = val;
+            if (vo >= 0) *(f32x4_t *)(out + (vo + (long)it * Vo + padd + pc) * 8) = val;
         }
     }
 }

@@ -860,29 +860,52 @@ extern "C" int mi355_tconv3d_ndhwc(const float *x_dev, int n, int d, int h, int 
     return rc;
 }
 
+// The single-op fp16 entry points take and return PLAIN NDHWC tensors (include/mi355_nnunet.h); the kernels work on
+// channel-blocked ones (common.h), so the operands pass through ndhwc_to_b8 / b8_to_ndhwc here.
+namespace {
+struct TmpBuf {
+    void *p = nullptr;
+    ~TmpBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
 extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
                                       const float *bias_host, int cout, int stride, int act, float slope, void *y_dev,
                                       void *stream) {
     MI355_TRY(require_device());
-    if (cin == 4 && stride == 1 && cout % 32 == 0) {
+    MI355_REQUIRE(stride == 1 || stride == 2, "conv stride %d unsupported", stride);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t Vi = (int64_t)d * h * w;
+    const int64_t Vo = (int64_t)((d - 1) / stride + 1) * ((h - 1) / stride + 1) * ((w - 1) / stride + 1);
+    MI355_REQUIRE(cout % 8 == 0, "fp16 conv needs cout %% 8 == 0 (got %d)", cout);
+    TmpBuf yb;
+    MI355_HIP(hipMalloc(&yb.p, (size_t)n * Vo * cout * 2));
+    int rc;
+    if (cin == 4 && stride == 1 && cout % 32 == 0) {  // the network's first-layer kernel: plain NDHW4 input
         StemWeights sw;
         MI355_TRY(stem_weights_upload(weight_host, bias_host, cin, cout, MI355_F16, &sw));
-        int rc = conv3d_stem(sw, x_dev, n, d, h, w, y_dev, nullptr, act, slope, (hipStream_t)stream);
+        rc = conv3d_stem(sw, x_dev, n, d, h, w, yb.p, nullptr, act, slope, s);
         g_last_conv_kernel = "conv3_stem_f16_kernel";
-        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (rc == MI355_OK) rc = b8_to_ndhwc((const _Float16 *)yb.p, n, cout, Vo, (_Float16 *)y_dev, s);
+        hipError_t e = hipStreamSynchronize(s);
         stem_weights_free(&sw);
         if (rc == MI355_OK && e != hipSuccess) { set_error("stem conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
         return rc;
     }
+    MI355_REQUIRE(cin % 8 == 0, "fp16 conv needs cin %% 8 == 0 (got %d)", cin);
+    TmpBuf xb;
+    MI355_HIP(hipMalloc(&xb.p, (size_t)n * Vi * cin * 2));
+    MI355_TRY(ndhwc_to_b8((const _Float16 *)x_dev, n, cin, Vi, (_Float16 *)xb.p, s));
     ConvWeightsH cw;
     MI355_TRY(conv_weights_upload_f16(weight_host, bias_host, cin, cin, cout, stride, &cw));
     ConvCallH c;
-    c.in0 = (const _Float16 *)x_dev; c.C0 = cin; c.N = n; c.Di = d; c.Hi = h; c.Wi = w; c.out = (_Float16 *)y_dev;
+    c.in0 = (const _Float16 *)xb.p; c.C0 = cin; c.N = n; c.Di = d; c.Hi = h; c.Wi = w; c.out = (_Float16 *)yb.p;
     c.act = act; c.slope = slope;
     const char *kname = nullptr;
-    int rc = conv3d_mfma_f16(cw, c, (hipStream_t)stream, &kname);
+    rc = conv3d_mfma_f16(cw, c, s, &kname);
     g_last_conv_kernel = kname ? kname : "";
-    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (rc == MI355_OK) rc = b8_to_ndhwc((const _Float16 *)yb.p, n, cout, Vo, (_Float16 *)y_dev, s);
+    hipError_t e = hipStreamSynchronize(s);
     conv_weights_free_f16(&cw);
     if (rc == MI355_OK && e != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
     return rc;
@@ -891,10 +914,17 @@ extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, in
 extern "C" int mi355_tconv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
                                        int cout, void *y_dev, void *stream) {
     MI355_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t Vi = (int64_t)d * h * w;
+    TmpBuf xb, yb;
+    MI355_HIP(hipMalloc(&xb.p, (size_t)n * Vi * cin * 2));
+    MI355_HIP(hipMalloc(&yb.p, (size_t)n * Vi * 8 * cout * 2));
     TConvWeightsH tw;
     MI355_TRY(tconv_weights_upload_f16(weight_host, cin, cout, &tw));
-    int rc = tconv2_mfma_f16(tw, (const _Float16 *)x_dev, n, d, h, w, (_Float16 *)y_dev, (hipStream_t)stream);
-    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    int rc = ndhwc_to_b8((const _Float16 *)x_dev, n, cin, Vi, (_Float16 *)xb.p, s);
+    if (rc == MI355_OK) rc = tconv2_mfma_f16(tw, (const _Float16 *)xb.p, n, d, h, w, (_Float16 *)yb.p, s);
+    if (rc == MI355_OK) rc = b8_to_ndhwc((const _Float16 *)yb.p, n, cout, Vi * 8, (_Float16 *)y_dev, s);
+    hipError_t e = hipStreamSynchronize(s);
     tconv_weights_free_f16(&tw);
     if (rc == MI355_OK && e != hipSuccess) { set_error("tconv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
     return rc;

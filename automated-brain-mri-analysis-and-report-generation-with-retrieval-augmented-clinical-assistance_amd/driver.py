@@ -25,7 +25,7 @@ MODEL2 = "nnUNetTrainerV2BraTSRegions_DA4_BN_BD_largeUnet_Groupnorm__nnUNetPlans
 MODALITY_MAP = {"t1": "0000", "t1ce": "0001", "t2": "0002", "flair": "0003"}  # reference :48-53
 
 
-def prepare_input(sample_dir, output_dir):
+def prepare_input(sample_dir, output_dir, quiet=False):
     """Reference :26-78.  BraTS names -> nnU-Net names, copied into ``output_dir``; a case with a
     missing modality is skipped with a warning.  Returns [(case, [4 paths in channel order])].
     (Cases are returned sorted; the reference iterates a Python set, i.e. in arbitrary order.)"""
@@ -36,7 +36,8 @@ def prepare_input(sample_dir, output_dir):
         parts = file.stem.replace(".nii", "").split("_")
         if parts[-1] in ["t1", "t1ce", "t2", "flair", "seg"]:
             cases.add("_".join(parts[:-1]))
-    print(f"Found {len(cases)} cases: {cases}")
+    if not quiet:
+        print(f"Found {len(cases)} cases: {cases}")
     prepared = []
     for case in sorted(cases):
         files, ok = [], True
@@ -48,7 +49,8 @@ def prepare_input(sample_dir, output_dir):
                     shutil.copy(src, dst)
                 files.append(str(dst))
             else:
-                print(f"[WARNING] Missing {mod} for {case}")
+                if not quiet:
+                    print(f"[WARNING] Missing {mod} for {case}")
                 ok = False
                 break
         if ok:
@@ -69,6 +71,25 @@ class LoadedModel:
     def close(self):
         for n in self.nets:
             n.close()
+
+
+class ModelCache:
+    """Loaded models keyed by (folder, folds, dtype).  The drop-in process uses one per run; the resident worker
+    (``brats_amd.worker``) keeps one for its lifetime, so a request finds both ensemble members on the device."""
+
+    def __init__(self):
+        self._models = {}
+
+    def get(self, model_folder, folds, dtype="f32") -> "LoadedModel":
+        key = (str(Path(model_folder).resolve()), tuple(int(f) for f in folds), dtype)
+        if key not in self._models:
+            self._models[key] = LoadedModel(checkpoint.load_model_folder(model_folder, folds, "model_final_checkpoint"), dtype=dtype)
+        return self._models[key]
+
+    def close(self):
+        for m in self._models.values():
+            m.close()
+        self._models.clear()
 
 
 def read_case(list_of_files: Sequence[str]):
@@ -145,15 +166,19 @@ def run_model_single_threaded(model_folder, input_folder, output_folder, folds=(
     return outputs
 
 
-def calculate_volumes(seg_path):
-    """Reference :217-243 - including its use of BraTS label 4 for ET on a file that holds
-    nnU-Net label 3 (so ET prints 0.00 before convert_labels_to_brats.py has run)."""
-    img = nifti.load(seg_path)
-    seg = img.data
-    voxel_volume_cm3 = float(np.prod(img.zooms)) / 1000.0
+def volumes_of(seg, zooms):
+    """Reference :217-243 on an array - including its use of BraTS label 4 for ET on a map that holds nnU-Net label 3
+    (so ET prints 0.00 before convert_labels_to_brats.py has run)."""
+    voxel_volume_cm3 = float(np.prod(zooms)) / 1000.0
     ncr, ed, et = int(np.sum(seg == 1)), int(np.sum(seg == 2)), int(np.sum(seg == 4))
     return {"NCR": ncr * voxel_volume_cm3, "ED": ed * voxel_volume_cm3, "ET": et * voxel_volume_cm3,
             "TC": (ncr + et) * voxel_volume_cm3, "WT": (ncr + ed + et) * voxel_volume_cm3}
+
+
+def calculate_volumes(seg_path):
+    """Reference :217-243 (reads the saved file, as the reference does)."""
+    img = nifti.load(seg_path)
+    return volumes_of(img.data, img.zooms)
 
 
 def ensemble_label_files(model1_output: Path, model2_output: Path, output_folder: Path, label_format: str = "nnunet"):
@@ -187,9 +212,92 @@ def ensemble_label_files(model1_output: Path, model2_output: Path, output_folder
     return finals
 
 
-def main(argv=None, script_dir=None):
+def run_both_models(model_dirs, input_folder, output_folder, folds, do_tta, step_size, dtype, label_format, cache: ModelCache):
+    """What reference :263-322 produces (model 1 over all cases, model 2 over all cases, label-round ensemble of the two
+    NIfTI files per case), computed in ONE pass per case: the four modalities are read, cropped and normalised once
+    (the reference preprocesses per model, :89), both members predict from the same device tensor, the ensemble takes
+    the two label volumes where they are - on the device - and the three NIfTI products of the case
+    (``temp_model1/<case>.nii.gz``, ``temp_model2/<case>.nii.gz``, ``<case>.nii.gz``) are compressed and written by
+    background threads while the next case runs.  Same files, same label values, same printed volumes; checkpoint loading of
+    both members and the copy of the inputs into ``temp_model{1,2}/temp_input`` overlap as well."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from . import evaluate
+    output_folder = Path(output_folder)
+    outs = [output_folder / f"temp_model{i}" for i in (1, 2)]
+    for md in model_dirs:
+        if not Path(md).exists():
+            print(f"[ERROR] Model not found: {md}")
+            sys.exit(1)
+    pool = ThreadPoolExecutor(max_workers=6)
+    t0 = time.perf_counter()
+    print(f"Loading models with folds: {tuple(folds)}")
+    dev = torch.cuda.current_device()
+
+    def load(md):  # (a new thread starts on device 0: the library is bound to THIS process's device)
+        torch.cuda.set_device(dev)
+        return cache.get(md, folds, dtype)
+    loaders = [pool.submit(load, md) for md in model_dirs]  # torch.load and the weight packing release the GIL
+    prepared = prepare_input(input_folder, outs[0] / "temp_input")
+    mirror = pool.submit(prepare_input, input_folder, outs[1] / "temp_input", True)
+    models = [f.result() for f in loaders]
+    print(f"Loaded {sum(len(m.nets) for m in models)} fold checkpoints of {len(models)} models in {time.perf_counter() - t0:.2f} s")
+    if not prepared:
+        print("[ERROR] No valid cases found!")
+        mirror.result()
+        return []
+    for o in outs:
+        o.mkdir(parents=True, exist_ok=True)
+    writes, finals = [], []
+    nxt = pool.submit(read_case, prepared[0][1])
+    for ci, (case_name, case_files) in enumerate(prepared):
+        print(f"\n{'=' * 70}\nProcessing case: {case_name}\n{'=' * 70}")
+        t1 = time.perf_counter()
+        raw, like = nxt.result()
+        if ci + 1 < len(prepared):
+            nxt = pool.submit(read_case, prepared[ci + 1][1])  # the next case's gunzip overlaps this case's prediction
+        t2 = time.perf_counter()
+        data, props = None, None
+        segs = []
+        for mi, model in enumerate(models):
+            if data is None:
+                data, props = preprocessing.preprocess_case(raw, plans=model.folder.plans, spacing_zyx=tuple(reversed(like.zooms)))
+                print(f"Data shape after preprocessing: {tuple(data.shape)}")
+            else:
+                preprocessing.check_plans(model.folder.plans, raw.shape[0])
+                preprocessing.check_spacing(model.folder.plans, tuple(reversed(like.zooms)), data.shape[1:])
+            print(f"Predicting {case_name} with model {mi + 1} ({len(model.nets)} folds)")
+            probs = predictor.predict_folds(model.nets, data, model.patch_size, step_size, do_tta, (0, 1, 2), True, model.nonlin)
+            lo = [b[0] for b in props["crop_bbox"]]
+            segs.append(ops.regions_to_labels(probs, (1, 2, 3) if model.folder.regions else None, lo, props["original_size_of_raw_data"]))
+        ens = evaluate.convert_labels(ops.label_ensemble(segs[0], segs[1]), label_format)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        host = [t.cpu().numpy() for t in (segs[0], segs[1], ens)]
+        final_output = output_folder / f"{case_name}.nii.gz"
+        for arr, path in zip(host, (outs[0] / f"{case_name}.nii.gz", outs[1] / f"{case_name}.nii.gz", final_output)):
+            # label volumes are written (x, y, z); the reference's ensemble saves with seg1's header = the input geometry
+            writes.append(pool.submit(nifti.save_like, path, np.ascontiguousarray(arr.transpose(2, 1, 0)), like))
+        v = volumes_of(host[2], like.zooms)
+        print(f"[OK] Completed: {final_output}  (read {t2 - t1:.2f} s, preprocess + predict {t3 - t2:.2f} s)")
+        print(f"\nTumor Volume Analysis for {case_name}:")
+        print(f"  NCR (Necrotic Core):        {v['NCR']:.2f} cm3")
+        print(f"  ED (Peritumoral Edema):     {v['ED']:.2f} cm3")
+        print(f"  ET (Enhancing Tumor):       {v['ET']:.2f} cm3")
+        print(f"  TC (Tumor Core):            {v['TC']:.2f} cm3")
+        print(f"  WT (Whole Tumor):           {v['WT']:.2f} cm3")
+        finals.append(final_output)
+    for w in writes:
+        w.result()
+    mirror.result()
+    pool.shutdown()
+    return finals
+
+
+def main(argv=None, script_dir=None, model_cache: ModelCache = None):
     """Reference :246-327.  --input/--output are the whole contract; the extra flags default to the
-    reference's hard-coded settings (5 folds, TTA on, step 0.5)."""
+    reference's hard-coded settings (5 folds, TTA on, step 0.5).  ``model_cache``: the resident worker's (models stay
+    loaded between requests); a plain process builds its own and frees it at the end."""
     ap = argparse.ArgumentParser(description="BraTS 2021 Brain Tumor Segmentation (MI355X-native)")
     ap.add_argument("--input", type=str, required=True, help="Input directory with BraTS sample data")
     ap.add_argument("--output", type=str, required=True, help="Output directory for segmentation results")
@@ -200,6 +308,9 @@ def main(argv=None, script_dir=None):
     ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
                     help="f32 (default): what the reference computes on its CPU path; f16: fp16 storage / fp32 accumulation, "
                          "the autocast setting the upstream trainer uses on a GPU (mixed_precision=True)")
+    ap.add_argument("--sequential", action="store_true",
+                    help="the reference's order of work (model 1 over all cases, model 2, then the ensemble of the two files) "
+                         "instead of one pass per case; same products")
     ap.add_argument("--label-format", dest="label_format", choices=("nnunet", "brats2025", "brats2021"), default="nnunet",
                     help="convention of the final <case>.nii.gz; 'nnunet' (default) is what the reference writes, the others "
                          "fold convert_labels_to_brats.py:34-55 into the export")
@@ -211,14 +322,24 @@ def main(argv=None, script_dir=None):
     print(f"RESULTS_FOLDER: {results_folder}\n")
     base = results_folder / "3d_fullres" / "Task500_BraTS2021"
     output_folder = Path(args.output)
-    outs = []
-    for i, name in enumerate((MODEL1, MODEL2), 1):
-        print("\n" + "=" * 70 + f"\nMODEL {i}: {name.split('__')[0]}\n" + "=" * 70)
-        outs.append(output_folder / f"temp_model{i}")
-        run_model_single_threaded(base / name, args.input, outs[-1], tuple(args.folds), not args.disable_tta,
-                                  args.step_size, dtype=args.dtype)
-    print("\n" + "=" * 70 + "\nENSEMBLING MODEL PREDICTIONS\n" + "=" * 70)
-    ensemble_label_files(outs[0], outs[1], output_folder, args.label_format)
+    if args.sequential:  # the reference's own order of work: model 1 over all cases, model 2, then the file-level ensemble
+        outs = []
+        for i, name in enumerate((MODEL1, MODEL2), 1):
+            print("\n" + "=" * 70 + f"\nMODEL {i}: {name.split('__')[0]}\n" + "=" * 70)
+            outs.append(output_folder / f"temp_model{i}")
+            run_model_single_threaded(base / name, args.input, outs[-1], tuple(args.folds), not args.disable_tta,
+                                      args.step_size, dtype=args.dtype)
+        print("\n" + "=" * 70 + "\nENSEMBLING MODEL PREDICTIONS\n" + "=" * 70)
+        ensemble_label_files(outs[0], outs[1], output_folder, args.label_format)
+    else:
+        print("\n" + "=" * 70 + f"\nMODELS: {MODEL1.split('__')[0]} + {MODEL2.split('__')[0]}\n" + "=" * 70)
+        cache = model_cache or ModelCache()
+        try:
+            run_both_models([base / MODEL1, base / MODEL2], args.input, output_folder, tuple(args.folds), not args.disable_tta,
+                            args.step_size, args.dtype, args.label_format, cache)
+        finally:
+            if model_cache is None:
+                cache.close()
     print("\n" + "=" * 70 + "\nSEGMENTATION COMPLETE!\n" + "=" * 70)
     print(f"Results saved to: {output_folder}")
     return 0

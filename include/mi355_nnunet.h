@@ -192,7 +192,8 @@ int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w, int cin, 
                        float *y_dev, void *stream);
 int mi355_tconv3d_ndhwc(const float *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
                         int cout, float *y_dev, void *stream);
-/* fp16-storage variants: x_dev / y_dev hold IEEE half NDHWC tensors (cin % 16 == 0, cout % 32 == 0). */
+/* fp16-storage variants: x_dev / y_dev hold IEEE half plain NDHWC tensors (cin % 16 == 0, cout % 32 == 0); inside the library
+ * fp16 activations are channel-blocked ([N][C/8][D][H][W][8]) and these entry points convert on the way in and out. */
 int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
                            const float *bias_host, int cout, int stride, int act, float slope, void *y_dev,
                            void *stream);

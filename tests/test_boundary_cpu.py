@@ -131,3 +131,55 @@ def test_plans_are_checked_not_assumed(amd):
     pp.check_spacing(other, (2.0, 1.0, 1.0), (70, 171, 137))
     with pytest.raises(pp.UnsupportedPlansError):
         pp.check_spacing(other, (1.0, 1.0, 1.0), (140, 171, 137))
+
+
+def test_worker_protocol_without_a_gpu(amd, tmp_path, monkeypatch):
+    """The resident worker's request / reply protocol and the client's fallbacks, with the driver's main() replaced by a
+    stand-in (no GPU here): output lines and the return code travel back, SystemExit becomes a return code, relative
+    paths are resolved against the CLIENT's working directory, a missing or dead socket means "run in-process" (None)."""
+    import io
+    import json
+    import socket
+    import threading
+    import time
+    from brats_amd import worker, driver
+    calls = []
+
+    def fake_main(argv, script_dir=None, model_cache=None):
+        print("running", " ".join(argv))
+        calls.append((list(argv), script_dir, model_cache is not None))
+        if "--boom" in argv:
+            raise SystemExit(1)
+        return 0
+
+    monkeypatch.setattr(driver, "main", fake_main)
+    sock = str(tmp_path / "w.sock")
+    assert worker.request(["--input", "x"], "/sd", sock) is None          # no worker: the caller runs in-process
+    t = threading.Thread(target=worker.serve, args=(sock,), daemon=True)
+    t.start()
+    for _ in range(100):
+        if os.path.exists(sock):
+            break
+        time.sleep(0.05)
+    out = io.StringIO()
+    argv = worker.absolutise(["--input", "in/case", "--output=out/case", "--folds", "0", "1"], cwd="/work")
+    assert argv == ["--input", "/work/in/case", "--output=/work/out/case", "--folds", "0", "1"]
+    assert worker.request(argv, "/sd", sock, out) == 0
+    assert out.getvalue() == "running " + " ".join(argv) + "\n" and calls[-1] == (argv, "/sd", True)
+    assert worker.request(["--boom"], "/sd", sock, io.StringIO()) == 1
+    with socket.socket(socket.AF_UNIX, socket.SOCK_STREAM) as sk:            # ping, then shutdown
+        sk.connect(sock)
+        fh = sk.makefile("rw")
+        fh.write(json.dumps({"cmd": "ping"}) + "\n")
+        fh.flush()
+        assert json.loads(fh.readline())["rc"] == 0
+    with socket.socket(socket.AF_UNIX, socket.SOCK_STREAM) as sk:
+        sk.connect(sock)
+        fh = sk.makefile("rw")
+        fh.write(json.dumps({"cmd": "shutdown"}) + "\n")
+        fh.flush()
+        assert json.loads(fh.readline())["rc"] == 0
+    t.join(5)
+    assert not t.is_alive() and not os.path.exists(sock)
+    monkeypatch.setenv("MI355_NO_WORKER", "1")
+    assert worker.request(argv, "/sd", sock) is None

@@ -65,6 +65,68 @@ def test_dropin_script_matches_oracle_driver(amd, gpu, tmp_path):
     assert "Tumor Volume Analysis" in res.stdout and "SEGMENTATION COMPLETE" in res.stdout
 
 
+def test_dropin_through_the_resident_worker_and_sequential_order(amd, gpu, tmp_path):
+    """The drop-in script as a thin client of ``python -m brats_amd.worker``: the worker keeps both models
+    resident, the client relays output and return code; its products are byte-identical to an in-process run
+    (MI355_NO_WORKER=1), and to ``--sequential`` (the reference's order of work: model 1, model 2, file-level ensemble).
+    A request for a missing model folder comes back as the reference's exit code 1, and the worker survives it."""
+    import time
+    patch = (32, 32, 32)
+    results = tmp_path / "nnUNet_results"
+    base = results / "3d_fullres" / "Task500_BraTS2021"
+    plans = amd.checkpoint.default_brats_plans(patch)
+    for name, preset, seed in ((amd.driver.MODEL1, "A", 60), (amd.driver.MODEL2, "B", 70)):
+        amd.checkpoint.save_model_folder(base / name, name.split("__")[0], [amd.synthetic.make_model(preset, seed=seed, num_pool=2, max_feat=128)[0]], plans)
+    case = "BraTS-GLI-00009-000"
+    case_dir = tmp_path / case
+    case_dir.mkdir()
+    _write_case(amd, case_dir, case, (36, 52, 44), seed=79)
+    sock = str(tmp_path / "w.sock")
+    script = os.path.join(ROOT, "run_brats2021_inference_singlethread.py")
+    env = dict(os.environ, MI355_WORKER_SOCKET=sock, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    worker = subprocess.Popen([sys.executable, "-m", "brats_amd.worker", "--socket", sock, "--results_folder", str(results), "--folds", "0"],
+                              env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        line = worker.stdout.readline()  # "[worker pid] listening on ... (2 models resident)"
+        assert "listening" in line and "2 models" in line, line + (worker.stdout.read() if worker.poll() is not None else "")
+        outs = {}
+        for tag, extra_env, extra_args in (("worker", {}, []), ("inprocess", {"MI355_NO_WORKER": "1"}, []),
+                                           ("sequential", {"MI355_NO_WORKER": "1"}, ["--sequential"])):
+            out = tmp_path / f"results_{tag}" / case
+            t0 = time.perf_counter()
+            res = subprocess.run([sys.executable, script, "--input", str(case_dir), "--output", str(out), "--results_folder", str(results),
+                                  "--folds", "0"] + extra_args, env=dict(env, **extra_env), cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+            assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+            assert "SEGMENTATION COMPLETE" in res.stdout and "Tumor Volume Analysis" in res.stdout
+            print(f"{tag}: {time.perf_counter() - t0:.2f} s wall")
+            outs[tag] = {rel: amd.nifti.load(out / rel).data for rel in (f"{case}.nii.gz", f"temp_model1/{case}.nii.gz", f"temp_model2/{case}.nii.gz")}
+            assert (out / "temp_model2" / "temp_input" / f"{case}_0000.nii.gz").exists()
+        for rel in outs["worker"]:
+            assert np.array_equal(outs["worker"][rel], outs["inprocess"][rel]), rel
+            # (model 2 is the GroupNorm member: its statistics are order-independent sums, so even that one is bit-stable)
+            assert np.array_equal(outs["worker"][rel], outs["sequential"][rel]), rel
+        # the reference's exit code for a missing model folder (:169-171) travels back through the worker
+        res = subprocess.run([sys.executable, script, "--input", str(case_dir), "--output", str(tmp_path / "nope"), "--results_folder",
+                              str(tmp_path / "no_such_results")], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+        assert res.returncode == 1 and "Model not found" in res.stdout
+        assert worker.poll() is None
+    finally:
+        sys.path.insert(0, ROOT)
+        import json
+        import socket as _socket
+        try:
+            with _socket.socket(_socket.AF_UNIX, _socket.SOCK_STREAM) as sk:
+                sk.connect(sock)
+                sk.sendall((json.dumps({"cmd": "shutdown"}) + "\n").encode())
+                sk.recv(100)
+        except OSError:
+            pass
+        try:
+            worker.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            worker.kill()
+
+
 def test_dropin_missing_models_exit_code(amd, gpu, tmp_path):
     (tmp_path / "in").mkdir()
     res = subprocess.run([sys.executable, os.path.join(ROOT, "run_brats2021_inference_singlethread.py"),

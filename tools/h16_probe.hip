@@ -3,6 +3,7 @@
 // of every workgroup spends its cycles.  Not part of the product.
 // Build: tools/build_probe.sh (h16_probe, h16_probe_stamps)
 #include "conv3d_f16.hip"
+#include "conv3d_f16_s2.hip"
 
 namespace mi355 {
 void set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
