@@ -852,6 +852,34 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
         *(__attribute__((address_space(3))) f32x4 *)dst = __builtin_bit_cast(f32x4, y);
     };
 
+    // The same work in five stages dealt over the gaps between a tap's MFMAs (round 3).  As one block behind the tap's second
+    // MFMA it cost 17 % of the kernel (conv3_f16_dma_kernel<true, true> 1010 against 1215 TFLOP/s without it): a gap hides about
+    // six VALU instructions (MI355X_MICROARCH.md, vector-instruction issue cost) and the block had 17 plus a ds_write, and the
+    // scale / shift rows were read from LDS in the gap that used them, i.e. with their full latency exposed.  Now: tap t reads
+    // the piece AND its scale / shift rows (stage 0); tap t + 1 does fma | mul | max | select + write behind MFMAs 2, 3, 4, 5.
+    struct AffStage { f32x4 raw; f16x8 sc, sh, y, ys; };
+    auto aff_s0 = [&](AffStage &st, unsigned pb, unsigned ta, unsigned tb, auto k_c) {
+        constexpr int k = decltype(k_c)::value;
+        st.raw = aff_read(pb, k_c);
+        st.sc = *(const __attribute__((address_space(3))) f16x8 *)(ta + (G::INTERLEAVED ? 0 : (k >> 2) * 16));
+        st.sh = *(const __attribute__((address_space(3))) f16x8 *)(tb + (G::INTERLEAVED ? 0 : (k >> 2) * 16));
+    };
+    auto aff_s1 = [&](AffStage &st) { st.y = __builtin_elementwise_fma(__builtin_bit_cast(f16x8, st.raw), st.sc, st.sh); };
+    auto aff_s2 = [&](AffStage &st) {
+        const f16x8 sl8 = {slope_in, slope_in, slope_in, slope_in, slope_in, slope_in, slope_in, slope_in};
+        st.ys = st.y * sl8;
+    };
+    auto aff_s3 = [&](AffStage &st) { st.y = __builtin_elementwise_max(st.y, st.ys); };
+    auto aff_s4 = [&](AffStage &st, int faces, unsigned pb, auto k_c) {
+        constexpr int k = decltype(k_c)::value;
+        unsigned pk = dma_pk[G::INTERLEAVED ? k : (k & 3)];
+        asm volatile("" : "+v"(pk));
+        const bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
+        unsigned dst = inside ? pb + (G::INTERLEAVED ? 4 * k * 1024 : (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024) : aff_junk;
+        asm volatile("" : "+v"(dst));
+        *(__attribute__((address_space(3))) f32x4 *)dst = __builtin_bit_cast(f32x4, st.y);
+    };
+
     // LDS byte offsets of this lane's voxel fragments in a brick buffer (tap (0,0,0)); fragment mf of wave w holds the
     // voxels v = (4 w + mf) * 32 + l31 of the tile: x = v & 7, y = (v >> 3) & 7, z = v >> 6
     int a_base[MF];
@@ -953,7 +981,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
 #ifdef MI355_H16_STAMPS
             unsigned long long t_seg = t_c0;
 #endif
-            f32x4 aff_raw = {0.f, 0.f, 0.f, 0.f};
+            AffStage aff_st;
             unsigned aff_pb = 0, aff_ta = 0, aff_tb = 0;
             if constexpr (INAFF) aff_bases(bufn, nxt, nch_eff, aff_pb, aff_ta, aff_tb);
             static_for<0, 27>([&](auto tap_c) {
@@ -969,14 +997,14 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                     constexpr int i = decltype(i_c)::value;
                     constexpr int mf = i >> 1, nf = i & 1;
                     acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[slot][nf], a[tap & 1][mf], acc[mf][nf], 0, 0, 0);
+                    // INAFF: piece ta / EVERY (read a tap ago) is normalised in this tap, one stage per MFMA gap
+                    constexpr int ta = tap - 11, tr = tap - 10;
+                    constexpr bool apply = INAFF && ta >= 0 && ta % G::EVERY == 0 && ta / G::EVERY < G::KD;
                     if constexpr (i == 1) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (INAFF) {  // (before this tap's LDS reads: the piece read a tap ago is complete, nothing is waited for)
-                            constexpr int ta = tap - 11, tr = tap - 10;
-                            if constexpr (ta >= 0 && ta % G::EVERY == 0 && ta / G::EVERY < G::KD)
-                                aff_apply(nfaces, std::integral_constant<int, ta / G::EVERY>{}, aff_pb, aff_ta, aff_tb, aff_raw);
+                        if constexpr (INAFF) {  // (before this tap's LDS reads: the piece landed long ago, nothing is waited for)
                             if constexpr (tr >= 0 && tr % G::EVERY == 0 && tr / G::EVERY < G::KD)
-                                aff_raw = aff_read(aff_pb, std::integral_constant<int, tr / G::EVERY>{});
+                                aff_s0(aff_st, aff_pb, aff_ta, aff_tb, std::integral_constant<int, tr / G::EVERY>{});
                         }
                         if constexpr (tap + 1 < 27) {
                             constexpr int nt = tap + 1;
@@ -986,6 +1014,14 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                             for (int m = 0; m < MF; ++m) a[(tap + 1) & 1][m] = *(lds_cf16x8 *)(ab[m] + off);
                         }
                         if constexpr (G::dma_tap(tap)) dma(nxt, nfaces, nch_eff, std::integral_constant<int, tap / G::EVERY>{}, bufn);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (apply && i >= 2 && i <= 5) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (i == 2) aff_s1(aff_st);
+                        if constexpr (i == 3) aff_s2(aff_st);
+                        if constexpr (i == 4) aff_s3(aff_st);
+                        if constexpr (i == 5) aff_s4(aff_st, nfaces, aff_pb, std::integral_constant<int, (ta >= 0 ? ta : 0) / G::EVERY>{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });

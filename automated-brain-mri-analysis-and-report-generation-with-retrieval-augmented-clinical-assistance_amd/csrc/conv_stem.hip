@@ -33,24 +33,32 @@ constexpr int S_BRICK = S_IX * S_IY * S_IZ;
 
 template <typename T>
 __device__ __forceinline__ void stem_stage(const T *in, char *lds, int n, int D, int H, int W, int oz0, int oy0, int ox0) {
-    // one piece per voxel: 4 channels = 16 B (fp32) / 8 B (fp16)
+    // one piece per voxel: 4 channels = 16 B (fp32) / 8 B (fp16).  Round 3: all six loads of a thread are issued before the
+    // first LDS write - as a load / select / write loop every iteration waited for its own load (six memory round trips
+    // in series per tile, with four workgroups per CU to hide them: the fp16 stem ran at 2.1 TB/s of output).
     constexpr int PB = 4 * sizeof(T);
-    for (int i = threadIdx.x; i < S_BRICK; i += 256) {
+    constexpr int ITER = (S_BRICK + 255) / 256;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef typename std::conditional<sizeof(T) == 4, f32x4, f32x2>::type piece_t;
+    piece_t v[ITER];
+    bool ok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = it * 256 + (int)threadIdx.x;
         const int r = i / S_IX, bx = i - r * S_IX;
         const int bz = r / S_IY, by = r - bz * S_IY;
         const int iz = oz0 - 1 + bz, iy = oy0 - 1 + by, ix = ox0 - 1 + bx;
-        const bool ok = ((unsigned)iz < (unsigned)D) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-        const size_t off = ok ? ((((size_t)n * D + iz) * H + iy) * W + ix) * 4 : 0;
-        if (sizeof(T) == 4) {
-            f32x4 v = *(const f32x4 *)((const float *)in + off);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            *(f32x4 *)(lds + (size_t)i * PB) = ok ? v : z;
-        } else {
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            f32x2 v = *(const f32x2 *)((const _Float16 *)in + off);
-            const f32x2 z = {0.f, 0.f};
-            *(f32x2 *)(lds + (size_t)i * PB) = ok ? v : z;
-        }
+        ok[it] = (i < S_BRICK) && ((unsigned)iz < (unsigned)D) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+        const size_t off = ok[it] ? ((((size_t)n * D + iz) * H + iy) * W + ix) * 4 : 0;
+        v[it] = *(const piece_t *)(in + off);
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = it * 256 + (int)threadIdx.x;
+        piece_t z;
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(piece_t) / 4); ++k) z[k] = 0.f;
+        if (i < S_BRICK) *(piece_t *)(lds + (size_t)i * PB) = ok[it] ? v[it] : z;
     }
 }
 
@@ -80,9 +88,12 @@ struct StemEpi {
     static constexpr int STORES = 32 * UNITS / 64;   // store instructions per fragment: 4 / 2
 };
 
-template <typename T>
+// STATS: -1 = iff p.stats (run time), 0 / 1 = compiled out / in (fp16 kernel: with the 32 statistics registers of the run-time
+// form the kernel needs 134 VGPRs and spilled at four workgroups per CU)
+template <typename T, int STATS = -1>
 __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &p, int n, int oz0, int oy0, int ox0,
                                               int co_blk, float *red, char *img_all) {
+    const bool do_stats = STATS < 0 ? p.stats != nullptr : STATS != 0;
     typedef StemEpi<T> E;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     float s1[16], s2[16];
@@ -106,7 +117,7 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
                 float x = acc[mf][4 * g + k] + bias[g][k];
                 x = fmaxf(x, x * slope);
                 val[k] = x;
-                if (ok && p.stats) { s1[4 * g + k] += x; s2[4 * g + k] += x * x; }
+                if (do_stats && ok) { s1[4 * g + k] += x; s2[4 * g + k] += x * x; }
             }
             char *dst = img + l31 * E::PITCH + (8 * g + 4 * half) * (int)sizeof(T);
             if (sizeof(T) == 4) *(f32x4 *)dst = val;
@@ -139,7 +150,7 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
             }
         }
     }
-    if (p.stats) {
+    if (do_stats) {
         __syncthreads();  // the brick is dead: reuse it for the cross-wave reduction
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -209,7 +220,8 @@ __global__ __launch_bounds__(256, 3) void conv3_stem_f32_kernel(StemArgs p) {
 // ---------------------------------------------------------------- fp16
 // weights: [cout block][(dz,dy) 9][lane 64][8 halfs]: lane (cout, h): h = 0 -> W[c0..3][dx0], W[c0..3][dx1];
 // h = 1 -> W[c0..3][dx2], 0, 0, 0, 0
-__global__ __launch_bounds__(256, 4) void conv3_stem_f16_kernel(StemArgs p) {
+template <bool STATS>
+__global__ __launch_bounds__(256, 3) void conv3_stem_f16_kernel(StemArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     int n, oz0, oy0, ox0;
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(256, 4) void conv3_stem_f16_kernel(StemArgs p) {
                 acc[mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[dz * 3 + dy], a, acc[mf], 0, 0, 0);
             }
         }
-    stem_epilogue<_Float16>(acc, p, n, oz0, oy0, ox0, co_blk, (float *)lds, lds + S_BRICK * 8);
+    stem_epilogue<_Float16, STATS ? 1 : 0>(acc, p, n, oz0, oy0, ox0, co_blk, (float *)lds, lds + S_BRICK * 8);
 }
 
 // ---------------------------------------------------------------- host
@@ -303,7 +315,8 @@ int conv3d_stem(const StemWeights &w, const void *in, int N, int D, int H, int W
     a.act = act; a.slope = slope;
     dim3 grid((unsigned)tiles, w.cout / 32);
     if (w.dtype == MI355_F16) {
-        hipLaunchKernelGGL(conv3_stem_f16_kernel, grid, dim3(256), (size_t)S_BRICK * 8 + 4 * StemEpi<_Float16>::WAVE_BYTES, s, a);
+        if (stats) hipLaunchKernelGGL(conv3_stem_f16_kernel<true>, grid, dim3(256), (size_t)S_BRICK * 8 + 4 * StemEpi<_Float16>::WAVE_BYTES, s, a);
+        else hipLaunchKernelGGL(conv3_stem_f16_kernel<false>, grid, dim3(256), (size_t)S_BRICK * 8 + 4 * StemEpi<_Float16>::WAVE_BYTES, s, a);
     } else {
         hipLaunchKernelGGL(conv3_stem_f32_kernel, grid, dim3(256), (size_t)S_BRICK * 16 + 4 * StemEpi<float>::WAVE_BYTES, s, a);
     }

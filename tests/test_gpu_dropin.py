@@ -87,7 +87,11 @@ def test_dropin_through_the_resident_worker_and_sequential_order(amd, gpu, tmp_p
     worker = subprocess.Popen([sys.executable, "-m", "brats_amd.worker", "--socket", sock, "--results_folder", str(results), "--folds", "0"],
                               env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     try:
-        line = worker.stdout.readline()  # "[worker pid] listening on ... (2 models resident)"
+        line = ""
+        for _ in range(50):  # (the ROCm runtime may print warnings of its own first)
+            line = worker.stdout.readline()  # "[worker pid] listening on ... (2 models resident)"
+            if "listening" in line or not line:
+                break
         assert "listening" in line and "2 models" in line, line + (worker.stdout.read() if worker.poll() is not None else "")
         outs = {}
         for tag, extra_env, extra_args in (("worker", {}, []), ("inprocess", {"MI355_NO_WORKER": "1"}, []),
