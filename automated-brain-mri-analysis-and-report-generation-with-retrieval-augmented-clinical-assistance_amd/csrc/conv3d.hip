@@ -1126,7 +1126,10 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
         if constexpr ((MI355_W2_ABL & 1) != 0) {
 #pragma unroll
             for (int f = 0; f < 16; ++f) asm volatile("" :: "a"(acc[f]));
-        } else if constexpr (PLAIN) {
+        } else if constexpr (EPI == 0 || EPI == 2) {
+            // (EPI == 2, round 3: the Instance/GroupNorm statistics ride on this epilogue - eight registers of running sums
+            //  over the values a lane stores - instead of materialising the 64 outputs for the shared conv_epilogue, which
+            //  spilled 59 registers and reloaded them from scratch in every tile)
             // Whole-line stores (see conv_epilogue_lines) through the brick buffer that has just been consumed - the other
             // one already holds the next tile's first chunk.  The output transform streams straight into the wave's LDS
             // image [fragment mf][voxel][cout] (8-B writes of two adjacent couts), so the 64 output values never exist
@@ -1182,6 +1185,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
             bool xok[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) xok[t] = cur.ox0 + 8 * t + srow < p.Wo;
+            float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};  // EPI == 2: sum x, sum x^2 of couts 4 spiece .. + 3
 #pragma unroll
             for (int mf = 0; mf < 4; ++mf) {
                 if constexpr ((MI355_W2_ABL & 64) != 0) continue;
@@ -1202,6 +1206,12 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                     asm("v_max_f32 %0, %1, %2" : "=v"(val[1]) : "v"(x0[1]), "v"(y0[1]));  // canonicalising max per value
                     asm("v_max_f32 %0, %1, %2" : "=v"(val[2]) : "v"(x1[0]), "v"(y1[0]));
                     asm("v_max_f32 %0, %1, %2" : "=v"(val[3]) : "v"(x1[1]), "v"(y1[1]));
+                    if constexpr (EPI == 2) {
+                        if (xok[t]) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { st1[k] += val[k]; st2[k] = fmaf(val[k], val[k], st2[k]); }
+                        }
+                    }
                     if constexpr ((MI355_W2_ABL & 32) != 0) asm volatile("" :: "v"(val));
                     // sc1: the line leaves the XCD's L2 with the store.  Nothing on this XCD reads it again, and kept in L2 the
                     // output (as many bytes as the input at Cin = Cout) evicts brick lines between the two half-line chunks of
@@ -1209,11 +1219,34 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                     else if (xok[t]) { float *gp = rowp + lane_off + t * t_stride; asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(gp), "v"(val) : "memory"); }
                 }
             }
+            if constexpr (EPI == 2) {
+                // the eight lanes with the same spiece (lane bits 3..5) hold the same four couts of different voxels
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float a = st1[k], b = st2[k];
+#pragma unroll
+                    for (int m = 8; m < 64; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+                    if (lane_e < 8) {
+                        red[(wave * 32 + 4 * lane_e + k) * 2 + 0] = a;
+                        red[(wave * 32 + 4 * lane_e + k) * 2 + 1] = b;
+                    }
+                }
+            }
             W2_T(t_e3);
             // the barrier keeps the next chunk's DMAs of a faster wave out of the staging area until every wave has read its
             // image back.  Raw barrier + lgkmcnt only: a __syncthreads() would also drain the stores (vmcnt(0)).
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if constexpr (EPI == 2) {
+                // (red is written again one tile later, behind this tile's barrier and the next tile's chunk barriers)
+                if (wave == 0) {  // (scalar test, lane id from the hardware: nothing here is a spilled invariant of the tile loop)
+                    const int c = lane_e >> 1, k = lane_e & 1;
+                    double tot = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) tot += (double)red[(w * 32 + c) * 2 + k];
+                    atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co0 + c) * 2 + k, quantise_partial(tot, k, (long)p.Do * p.Ho * p.Wo));  // exact, hence order-independent (common.h)
+                }
+            }
             W2_T(t_e4);
             W2_ACC(8, t_e3, t_e4);
         } else if constexpr (EPI == 1) {
@@ -1286,32 +1319,6 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                     if (ok) p.head_out[((int64_t)cur.n * p.head_ncls + c) * Vo + vi] = v + p.head_b[c];
                 }
             }
-        } else {
-            f32x16 out[4][1];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2 P[4][2];
-#pragma unroll
-                for (int fz = 0; fz < 4; ++fz) {
-                    const f32x2 a0 = {acc[fz * 4 + 0][r], acc[fz * 4 + 0][r + 1]}, a1 = {acc[fz * 4 + 1][r], acc[fz * 4 + 1][r + 1]};
-                    const f32x2 a2 = {acc[fz * 4 + 2][r], acc[fz * 4 + 2][r + 1]}, a3 = {acc[fz * 4 + 3][r], acc[fz * 4 + 3][r + 1]};
-                    P[fz][0] = pk_add(pk_add(a0, a1), a2);
-                    P[fz][1] = pk_sub(pk_sub(a1, a2), a3);
-                }
-#pragma unroll
-                for (int yy = 0; yy < 2; ++yy) {
-                    const f32x2 o0 = pk_add(pk_add(P[0][yy], P[1][yy]), P[2][yy]);
-                    const f32x2 o1 = pk_sub(pk_sub(P[1][yy], P[2][yy]), P[3][yy]);
-                    out[0 + yy][0][r] = o0[0]; out[0 + yy][0][r + 1] = o0[1];
-                    out[2 + yy][0][r] = o1[0]; out[2 + yy][0][r + 1] = o1[1];
-                }
-            }
-            // the shared epilogue with a 2-row y tile places fragment mf of wave w at z = 2w + (mf>>1), y = mf&1: shift its
-            // origin to this wave's block (z = 2bz + (mf>>1), y = 2by + (mf&1))
-            ConvArgs q = p;
-            q.lx = 5; q.ly = 1;
-            conv_epilogue<4, 1>(out, q, cur.n, cur.oz0 + 2 * bz - 2 * wave, cur.oy0 + 2 * by, cur.ox0, (int)blockIdx.y * 32, red,
-                                /*sync_before_red=*/false);
         }
         cur = nxt_tile;
         if (ntile < hi) {  // the next tile's first weight fragments (same cout block, chunk 0); they land while the accumulators are reset

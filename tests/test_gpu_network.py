@@ -394,3 +394,63 @@ def test_tta_full_tile_matches_oracle(amd, gpu, tile128, name, seed):
         print(f"PARITY TTA 128^3 {name} {dtype}: prob err {err:.2e}, Dice {d['mean']:.6f}")
         assert err <= tol and d["mean"] >= dice_min
         net.close()
+
+
+def test_five_fold_mean_at_full_patch(amd, gpu, tile128):
+    """The reference's fold ensemble at the size it runs (run_brats2021_inference_singlethread.py:161 folds=(0, 1, 2, 3, 4),
+    :112-128: one prediction per fold, np.mean over them): five model-A folds (seeds 7..11, as bench.py's reference_setting
+    block) through predict_folds on one 128^3 volume (= one tile) against the mean of five CPU-oracle forwards, fp32 and fp16."""
+    sds = [amd.synthetic.make_model("A", seed=7 + k)[0] for k in range(5)]
+    cfg = unet_ref.default_cfg(norm="batch")
+    x = torch.from_numpy(tile128)
+    ref = np.mean([torch.sigmoid(unet_ref.unet_forward(sd, x, cfg))[0].numpy() for sd in sds], axis=0)  # driver :128
+    for dtype, tol, dice_min in (("f32", PROB_TOL, 0.9999), ("f16", 2e-2, 0.999)):
+        nets = [amd.UNet(sd, norm="batch", dtype=dtype) for sd in sds]
+        got = amd.predictor.predict_folds(nets, tile128[0], (128, 128, 128), 0.5, False, (0, 1, 2), True, "sigmoid").cpu().numpy()
+        err = float(np.abs(got - ref).max())
+        d = tiler_ref.brats_region_dice(tiler_ref.regions_to_labels(got), tiler_ref.regions_to_labels(ref))
+        print(f"PARITY 5-fold mean 128^3 A {dtype}: prob err {err:.2e}, Dice {d['mean']:.6f}")
+        assert err <= tol and d["mean"] >= dice_min
+        for n in nets:
+            n.close()
+
+
+@pytest.fixture(scope="module")
+def bench_tile(amd, gpu):
+    """The first 128^3 tile of bench.py's timed synthetic brain volume (synthetic.make_volume(1000), cropped and z-scored on
+    the device): smooth low-frequency tissue inside an ellipsoidal mask, exact zeros outside - not Gaussian noise."""
+    data, _ = amd.preprocessing.preprocess_case(amd.synthetic.make_volume(seed=1000), gpu)
+    steps = [amd.ops.compute_steps(128, max(128, data.shape[1 + a]), 0.5) for a in range(3)]
+    t = data[:, steps[0][0]:steps[0][0] + 128, steps[1][0]:steps[1][0] + 128, steps[2][0]:steps[2][0] + 128]
+    pad = [128 - t.shape[1 + i] for i in range(3)]
+    return torch.nn.functional.pad(t, (0, pad[2], 0, pad[1], 0, pad[0]))[None].contiguous().cpu().numpy()
+
+
+@pytest.mark.parametrize("name,seed", [("A", 7), ("B", 8)])
+def test_bench_tile_f16_margin(amd, gpu, bench_tile, name, seed):
+    """VERDICT r2 (weak #2): the fp16 gates were only ever applied to Gaussian-noise tiles; this is the tile the bench's
+    parity block uses.  Gates: the north_star's Dice >= 0.999 on all voxels, logits within 7 % of their spread, and
+    probabilities within 0.15 - on this tile 0.6 % of the logits lie within 0.05 of the decision threshold (the synthetic
+    seg head is scaled for confident logits, but a brain-shaped input leaves a wide transition band), where a logit error
+    of 0.8 (6 % of the spread, the worst voxel of 6 M) moves a probability by 0.11.  Measured (round 3, tools/f16_margin.py):
+    A: logit max 0.49 / rms 0.013 of spread 24.2, probability 0.089, 575 of 2.1 M labels differ, Dice 0.999865;
+    B: logit max 0.81 / rms 0.017 of spread 13.5, probability 0.113, 1875 labels, Dice 0.999498 - and 0.999538 with the
+    producer's normalisation as a separate fp32 pass (MI355_FUSE_NORM=0): the fused fp16 scale / shift is not what the
+    margin is made of, the 2^-11 rounding of ~50 stored activations is."""
+    sd, meta = amd.synthetic.make_model(name, seed=seed)
+    ref = unet_ref.unet_forward(sd, torch.from_numpy(bench_tile), unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])).numpy()
+    net = amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"], dtype="f16")
+    got = net(torch.from_numpy(bench_tile).to(gpu)).cpu().numpy()
+    net.close()
+    spread = float(ref.std())
+    err = np.abs(got.astype(np.float64) - ref)
+    pg, pr = 1 / (1 + np.exp(-got.astype(np.float64))), 1 / (1 + np.exp(-ref.astype(np.float64)))
+    lg, lr = tiler_ref.regions_to_labels(pg[0].astype(np.float32)), tiler_ref.regions_to_labels(pr[0].astype(np.float32))
+    d = tiler_ref.brats_region_dice(lg, lr)
+    print(f"PARITY bench tile {name} f16: logit err max {err.max():.3f} rms {np.sqrt((err ** 2).mean()):.4f} (spread {spread:.2f}), "
+          f"prob err {np.abs(pg - pr).max():.3f}, {int((lg != lr).sum())} labels differ, Dice {d['mean']:.6f}")
+    assert d["mean"] >= 0.999 and min(d["WT"], d["TC"], d["ET"]) >= 0.999, d
+    assert err.max() <= 7e-2 * spread and np.sqrt((err ** 2).mean()) <= 3e-3 * spread
+    assert np.abs(pg - pr).max() <= 0.15
+    sure = (np.abs(ref[0]) >= 1.0).all(0)
+    assert tiler_ref.brats_region_dice(lg[sure], lr[sure])["mean"] >= 0.9999
