@@ -381,8 +381,12 @@ __global__ __launch_bounds__(256) void splitk_finish_f16_kernel(const float *par
 // the 32 contiguous bytes of a voxel's chunk with two adjacent lanes, so an instruction touches half the 128-B lines that
 // the LDS-DMA stride-2 kernel's plane-wise 16-B pieces touch - and the line rate of the L1, not the matrix pipe or the
 // L2, is what held that kernel at 0.13-0.16 of the fp16 peak.
-template <int MF, int NF, bool HEAD = false, bool INAFF = false, int STRIDE = 1>
+// WHOLE (round 3): the volume is a whole number of tiles (host check), i.e. every network layer at the reference's patch
+// sizes: the instantiation carries neither the exact per-axis test of overhanging tiles nor its 11 wave-uniform branches
+// per chunk (each a basic-block boundary with waits of its own); INAFF is only built with WHOLE.
+template <int MF, int NF, bool HEAD = false, bool INAFF = false, int STRIDE = 1, bool WHOLE = false>
 __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p) {
+    static_assert(!INAFF || WHOLE, "the fused input normalisation is built for whole-tile volumes only");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     constexpr int SLOTS = STRIDE == 2 ? 13 : (MF == 4 ? 11 : 8);  // 16-B staging pieces per thread and chunk
     constexpr int BD = 3;                    // weight fragments fetched BD tap-steps ahead; the ring phase must
@@ -458,10 +462,14 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
                ((STRIDE * (tc.ox0 + (1 << p.lx) - 1) + 1 >= p.Wi) << 5);
     };
     auto tile_ragged = [&](const TileCoord &tc) {
-        return (STRIDE * (tc.oz0 + (1 << p.lz) - 1) + 1 > p.Di) | (STRIDE * (tc.oy0 + (1 << p.ly) - 1) + 1 > p.Hi) |
-               (STRIDE * (tc.ox0 + (1 << p.lx) - 1) + 1 > p.Wi);
+        if constexpr (WHOLE) return false;
+        else return (bool)((STRIDE * (tc.oz0 + (1 << p.lz) - 1) + 1 > p.Di) | (STRIDE * (tc.oy0 + (1 << p.ly) - 1) + 1 > p.Hi) |
+                           (STRIDE * (tc.ox0 + (1 << p.lx) - 1) + 1 > p.Wi));
     };
     const int dst0 = (tid & 1) * p.plane_bytes + (tid >> 1) * 16;  // LDS byte offset of slot 0; slot r is 128 voxels further
+    // Slots beyond the brick (and every slot when there is no next chunk) are written to a junk area of 16 B per thread
+    // instead of being predicated: a predicated ds_write is an exec-mask branch per slot in the tap loop (round 3)
+    const int junk_dst = 2 * buf_bytes + 4 * NF * 32 * 2 * (int)sizeof(float) + tid * 16;
     auto stage_issue = [&](const TileCoord &tc, int faces, bool ragged, int ch, int r) {
         const int cglob = ch * 16;
         const half_t *src; int Csrc, coff;
@@ -559,13 +567,13 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
         for (int r = 0; r < SLOTS; ++r) {
             f32x4 v = stage_issue(cur, tile_faces(cur), tile_ragged(cur), 0, r);
-            if constexpr (INAFF) v = in_affine(v, sc0, sh0, sl0);
-            if (slot_valid(r)) {
-                *(f32x4 *)(lds_raw + dst0 + r * 2048) = v;
-                if constexpr (INAFF) {  // padding follows the norm: out-of-volume pieces are zero, not act(shift)
-                    if (!slot_inside(cur, tile_faces(cur), tile_ragged(cur), r)) *(f32x4 *)(lds_raw + dst0 + r * 2048) = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+            if constexpr (INAFF) {  // padding follows the norm: out-of-volume pieces are zero, not act(shift)
+                v = in_affine(v, sc0, sh0, sl0);
+                const bool in = slot_inside(cur, tile_faces(cur), tile_ragged(cur), r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = in ? v[j] : 0.f;
             }
+            *(f32x4 *)(lds_raw + (slot_valid(r) ? dst0 + r * 2048 : junk_dst)) = v;
         }
     }
     f16x8 bq[BD][NF];
@@ -640,12 +648,18 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
                 constexpr int r = decltype(r_c)::value;
                 constexpr int wr = r + FLIGHT < 26 ? r + FLIGHT : 26;
                 if constexpr (wr == tap) {
-                    if (have_next && slot_valid(r)) {
-                        if constexpr (INAFF) st_v[r] = in_affine(st_v[r], sc_n, sh_n, sl_n);
-                        *(f32x4 *)(bufn + dst0 + r * 2048) = st_v[r];
-                        if constexpr (INAFF) {  // (second write, same wave, in order: zero where the piece lies outside the volume)
-                            if (!slot_inside(nxt, nfaces, nragged, r)) *(f32x4 *)(bufn + dst0 + r * 2048) = f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
+                    if constexpr (INAFF) {
+                        // (round 3: the out-of-volume pieces are zeroed by four selects - as a second, masked LDS write the test
+                        //  was a branch per slot, 49 more basic-block boundaries in the tap loop, each with its own waits)
+                        st_v[r] = in_affine(st_v[r], sc_n, sh_n, sl_n);
+                        const bool in = slot_inside(nxt, nfaces, nragged, r);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) st_v[r][j] = in ? st_v[r][j] : 0.f;
+                    }
+                    {
+                        int dsel = (have_next && slot_valid(r)) ? (buf ^ 1) * buf_bytes + dst0 + r * 2048 : junk_dst;
+                        asm volatile("" : "+v"(dsel));  // (a select, not a branch)
+                        *(f32x4 *)(lds_raw + dsel) = st_v[r];
                     }
                 }
             });
@@ -1263,6 +1277,13 @@ bool conv3d_f16_fuses_input_norm(const ConvWeightsH &w, const ConvCallH &c) {
     static int splitk = -1;
     if (splitk < 0) { const char *e = getenv("MI355_SPLITK"); splitk = (e && e[0] == '0') ? 0 : 1; }
     if (splitk && !c.stats && w.cin_pad / 16 >= 8) return false;  // might take the split-K path: keep it simple
+    // the register-staged kernels apply the norm on volumes that are whole tiles only (512- or 256-voxel tiles, whichever
+    // the launch picks; the LDS-DMA kernel's 8 x 8 x 8 tiles divide whatever these divide)
+    for (int vox : {512, 256}) {
+        int lz, ly, lx;
+        choose_tile_h(c.Di, c.Hi, c.Wi, 1, vox, &lz, &ly, &lx);
+        if (c.Di % (1 << lz) || c.Hi % (1 << ly) || c.Wi % (1 << lx)) return false;
+    }
     return true;
 }
 
@@ -1375,28 +1396,39 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         MI355_REQUIRE((long)a.IZ * c.Hi * c.Wi < (1l << 24) && ((long)a.IZ * c.Hi * c.Wi + (long)c.Di * c.Hi * c.Wi) * 16 < (1l << 31),
                       "volume too large for the 32-bit staging offsets");
         a.total_tiles = (int)tiles;
-        const size_t lds_bytes = (size_t)4 * a.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float);
+        const size_t lds_bytes = (size_t)4 * a.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float) + 256 * 16;  // bricks, statistics, junk slots
         MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
         int gx = 512 / gy;
         gx = gx < 8 ? 8 : (gx / 8) * 8;
         const int need = (int)((tiles + 7) / 8) * 8;
         if (gx > need) gx = need;
         dim3 grid(gx, gy);
-        if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false, false, 1>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false, false, 1>" : "conv3_f16_mfma_pipe_kernel<2, 2, false, false, 1>");
+        const bool whole = a.Do % (1 << a.lz) == 0 && a.Ho % (1 << a.ly) == 0 && a.Wo % (1 << a.lx) == 0;
+        // (names = the instantiations as rocprofv3 prints them: <MF, NF, HEAD, INAFF, STRIDE, WHOLE>)
         if (c.head_out) {
             MI355_REQUIRE(w.nf == 1, "fused head: fp16 path supports Cout = 32 only");
-            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, true, false, 1>" : "conv3_f16_mfma_pipe_kernel<2, 1, true, false, 1>";
-            static size_t attr_head[2] = {48 * 1024, 48 * 1024};  // one slot per kernel: the attribute is per function
-            if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, true>, a, grid, lds_bytes, s, &attr_head[0]);
-            return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, true>, a, grid, lds_bytes, s, &attr_head[1]);
+            static size_t attr_head[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};  // one slot per kernel: the attribute is per function
+            if (MF == 4 && whole) { if (kernel_name) *kernel_name = "conv3_f16_mfma_pipe_kernel<4, 1, true, false, 1, true>"; return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, true, false, 1, true>, a, grid, lds_bytes, s, &attr_head[0]); }
+            if (MF == 4) { if (kernel_name) *kernel_name = "conv3_f16_mfma_pipe_kernel<4, 1, true, false, 1, false>"; return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, true>, a, grid, lds_bytes, s, &attr_head[1]); }
+            if (kernel_name) *kernel_name = "conv3_f16_mfma_pipe_kernel<2, 1, true, false, 1, false>";
+            return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, true>, a, grid, lds_bytes, s, &attr_head[2]);
         }
         if (c.in_scale) {  // the producer's normalisation + activation applied while the brick is staged
+            MI355_REQUIRE(whole, "fused input normalisation needs a volume of whole tiles (conv3d_f16_fuses_input_norm)");
             static size_t attr_aff[3] = {48 * 1024, 48 * 1024, 48 * 1024};
-            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false, true, 1>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false, true, 1>" : "conv3_f16_mfma_pipe_kernel<2, 2, false, true, 1>");
-            if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, false, true>, a, grid, lds_bytes, s, &attr_aff[0]);
-            if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, false, true>, a, grid, lds_bytes, s, &attr_aff[1]);
-            return launch_h(conv3_f16_mfma_pipe_kernel<2, 2, false, true>, a, grid, lds_bytes, s, &attr_aff[2]);
+            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false, true, 1, true>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false, true, 1, true>" : "conv3_f16_mfma_pipe_kernel<2, 2, false, true, 1, true>");
+            if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, false, true, 1, true>, a, grid, lds_bytes, s, &attr_aff[0]);
+            if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, false, true, 1, true>, a, grid, lds_bytes, s, &attr_aff[1]);
+            return launch_h(conv3_f16_mfma_pipe_kernel<2, 2, false, true, 1, true>, a, grid, lds_bytes, s, &attr_aff[2]);
         }
+        if (whole) {
+            static size_t attr_w[3] = {48 * 1024, 48 * 1024, 48 * 1024};
+            if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false, false, 1, true>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false, false, 1, true>" : "conv3_f16_mfma_pipe_kernel<2, 2, false, false, 1, true>");
+            if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1, false, false, 1, true>, a, grid, lds_bytes, s, &attr_w[0]);
+            if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1, false, false, 1, true>, a, grid, lds_bytes, s, &attr_w[1]);
+            return launch_h(conv3_f16_mfma_pipe_kernel<2, 2, false, false, 1, true>, a, grid, lds_bytes, s, &attr_w[2]);
+        }
+        if (kernel_name) *kernel_name = MF == 4 ? "conv3_f16_mfma_pipe_kernel<4, 1, false, false, 1, false>" : (w.nf == 1 ? "conv3_f16_mfma_pipe_kernel<2, 1, false, false, 1, false>" : "conv3_f16_mfma_pipe_kernel<2, 2, false, false, 1, false>");
         if (MF == 4) return launch_h(conv3_f16_mfma_pipe_kernel<4, 1>, a, grid, lds_bytes, s, &attr[0]);
         if (w.nf == 1) return launch_h(conv3_f16_mfma_pipe_kernel<2, 1>, a, grid, lds_bytes, s, &attr[1]);
         return launch_h(conv3_f16_mfma_pipe_kernel<2, 2>, a, grid, lds_bytes, s, &attr[2]);
@@ -1413,7 +1445,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         ConvArgsH b = a;
         fill_geometry_h(b, 2, 128);
         const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
-        const size_t lds_bytes = (size_t)4 * b.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float);
+        const size_t lds_bytes = (size_t)4 * b.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float) + 256 * 16;
         if (s2pipe && tiles * gy >= 768 && tiles < (1l << 30) && b.IX * b.IY * b.IZ <= 13 * 128 && lds_bytes <= 160 * 1024 &&
             (long)b.IZ * c.Hi * c.Wi < (1l << 24) && ((long)b.IZ * c.Hi * c.Wi + (long)c.Di * c.Hi * c.Wi) * 16 < (1l << 31) && !c.in_scale) {
             b.total_tiles = (int)tiles;
@@ -1421,7 +1453,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
             gx = gx < 8 ? 8 : (gx / 8) * 8;
             const int need = (int)((tiles + 7) / 8) * 8;
             if (gx > need) gx = need;
-            if (kernel_name) *kernel_name = "conv3_f16_mfma_pipe_kernel<1, 2, false, false, 2>";
+            if (kernel_name) *kernel_name = "conv3_f16_mfma_pipe_kernel<1, 2, false, false, 2, false>";
             static size_t attr_s2 = 48 * 1024;
             return launch_h(conv3_f16_mfma_pipe_kernel<1, 2, false, false, 2>, b, dim3(gx, gy), lds_bytes, s, &attr_s2);
         }

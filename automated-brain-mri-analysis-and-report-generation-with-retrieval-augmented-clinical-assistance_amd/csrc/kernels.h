@@ -104,7 +104,7 @@ struct TConvWeightsH {
 int tconv_weights_upload_f16(const float *w_host, int cin, int cout, TConvWeightsH *out);
 void tconv_weights_free_f16(TConvWeightsH *w);
 int tconv2_mfma_f16(const TConvWeightsH &w, const _Float16 *in, int N, int D, int H, int W, _Float16 *out,
-                    hipStream_t s);
+                    hipStream_t s, const char **kernel_name = nullptr);
 
 // ---------------------------------------------------------------- normalisation
 // stats [N][C][2] doubles -> scale/shift [N][C] so that y = x*scale + shift.

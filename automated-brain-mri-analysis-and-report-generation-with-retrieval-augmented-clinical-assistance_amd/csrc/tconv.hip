@@ -395,6 +395,99 @@ __global__ __launch_bounds__(256, 2) void tconv2_f16_mfma_v2_kernel(const _Float
     }
 }
 
+// Version 3 (round 3): version 2 made persistent, with the weights in registers.  A workgroup of version 2 read its whole
+// weight block from the L2 for every 128 voxels - Cin x 512 B, as many bytes as the 64 KiB of output it stores (Cin = 128) -
+// so the L1 moved 2.5 x the HBM traffic of a kernel that should be bound by its output stream.  Here a workgroup keeps the
+// two parities' weight fragments of its wave in registers (8 G VGPRs, G = Cin / 16 <= 8 at compile time) and strides over
+// the voxel tiles; per tile only the 128 x Cin input block comes through the L1.
+template <int G>
+__global__ __launch_bounds__(256, 2) void tconv2_f16_mfma_v3_kernel(const _Float16 *__restrict__ in,
+                                                                const _Float16 *__restrict__ wp, _Float16 *out, int M,
+                                                                int Cout, int D, int H, int W, FastDiv divW,
+                                                                FastDiv divH, FastDiv divD) {
+    constexpr int Cin = G * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nblk = Cout >> 5;
+    const int nb = (int)blockIdx.y;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int XPLANE = 128 * 8 + 8;  // halfs
+    constexpr int NP = Cin / 8;          // 8-channel blocks of the input (all of them staged at once: <= 16 x 2 KiB)
+    __shared__ __attribute__((aligned(16))) _Float16 xs[NP * XPLANE];
+    __shared__ __attribute__((aligned(16))) _Float16 tr[4][32 * 64];
+    f16x8 wreg[2][G];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int g = 0; g < G; ++g) wreg[pp][g] = *(const f16x8 *)(wp + ((size_t)((wave * 2 + pp) * nblk + nb) * G + g) * 512 + lane * 8);
+    const long Vi = (long)D * H * W;
+    const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+    const long Vo = (long)Do * Ho * Wo;
+    const int pa = wave >> 1, pb = wave & 1;  // parities 2w, 2w+1 = (pa, pb, 0) and (pa, pb, 1)
+    const long padd = ((long)pa * Ho + pb) * Wo;  // voxels
+    _Float16 *mytr = tr[wave];
+    const int ntiles = (M + 127) >> 7;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+        const int m0 = tile * 128;
+        if (tile != (int)blockIdx.x) __syncthreads();  // the previous tile's fragment reads are done
+#pragma unroll
+        for (int k2 = 0; k2 < NP / 2; ++k2) {  // 128 voxels x NP blocks = NP / 2 pieces per thread
+            const int i = k2 * 256 + tid, v = i & 127, q = i >> 7;
+            int vg = m0 + v;
+            if (vg >= M) vg = M - 1;
+            const uint32_t ns = fdiv(fdiv(fdiv((uint32_t)vg, divW), divH), divD);
+            *(f32x4_t *)(xs + q * XPLANE + v * 8) = *(const f32x4_t *)(in + (((long)ns * NP + q) * Vi + (vg - (long)ns * Vi)) * 8);
+        }
+        __syncthreads();
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pp][mf][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            f16x8 x[4];
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) x[mf] = *(const f16x8 *)(xs + (2 * g + half) * XPLANE + (mf * 32 + l31) * 8);
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    acc[pp][mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[pp][g], x[mf], acc[pp][mf], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int v = m0 + mf * 32 + l31;
+            const int vc = v < M ? v : M - 1;
+            const uint32_t q1 = fdiv((uint32_t)vc, divW);
+            const int x = vc - (int)q1 * W;
+            const uint32_t q2 = fdiv(q1, divH);
+            const int y = (int)q1 - (int)q2 * H;
+            const uint32_t n = fdiv(q2, divD);
+            const int z = (int)q2 - (int)n * D;
+            const long vox000 = v < M ? ((long)n * (Cout >> 3) + nb * 4) * Vo + (((long)2 * z) * Ho + 2 * y) * Wo + 2 * x : -1;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f16x4 hv = {(_Float16)acc[pp][mf][4 * g4], (_Float16)acc[pp][mf][4 * g4 + 1],
+                                      (_Float16)acc[pp][mf][4 * g4 + 2], (_Float16)acc[pp][mf][4 * g4 + 3]};
+                    *(f16x4 *)(mytr + l31 * 64 + (((pp * 4 + g4) ^ (l31 & 7)) << 3) + half * 4) = hv;
+                }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = lane >> 1, pc = lane & 1;
+                const f32x4_t val = *(const f32x4_t *)(mytr + r * 64 + (((pc * 4 + it) ^ (r & 7)) << 3));
+                const int lo = __shfl((int)(vox000 & 0xffffffff), r), hi = __shfl((int)(vox000 >> 32), r);
+                const long vo = ((long)hi << 32) | (unsigned)lo;
+                if (vo >= 0) *(f32x4_t *)(out + (vo + (long)it * Vo + padd + pc) * 8) = val;
+            }
+        }
+    }
+}
+
 // pack: [pos][cout block][g][lane][j 0..7]; cout = nb*32 + (lane&31), cin = g*16 + (lane>>5)*8 + j
 int tconv_weights_upload_f16(const float *w_host, int cin, int cout, TConvWeightsH *out) {
     MI355_REQUIRE(cin % 16 == 0 && cout % 32 == 0, "fp16 tconv %d->%d: need cin %% 16 == 0 and cout %% 32 == 0", cin, cout);
@@ -424,11 +517,29 @@ void tconv_weights_free_f16(TConvWeightsH *w) {
 }
 
 int tconv2_mfma_f16(const TConvWeightsH &w, const _Float16 *in, int N, int D, int H, int W, _Float16 *out,
-                    hipStream_t s) {
+                    hipStream_t s, const char **kernel_name) {
+    if (kernel_name) *kernel_name = "tconv2_f16_mfma_v2_kernel";
     const long M = (long)N * D * H * W;
     MI355_REQUIRE(M > 0 && M < (1l << 30), "tconv: %ld voxels out of range", M);
     static int v1 = -1;
     if (v1 < 0) { const char *e = getenv("MI355_TCONV_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
+    static int v3 = -1;
+    if (v3 < 0) { const char *e = getenv("MI355_TCONV_V3"); v3 = (e && e[0] == '0') ? 0 : 1; }
+    const long ntiles = (M + 127) / 128;
+    if (!v1 && v3 && (w.cin == 32 || w.cin == 64 || w.cin == 128) && ntiles >= 1024) {
+        // persistent: two workgroups per CU and cout block share the 512 resident slots
+        const int nblk = w.cout / 32;
+        long gx = 512 / nblk;
+        if (gx < 8) gx = 8;
+        if (gx > ntiles) gx = ntiles;
+        dim3 grid3((unsigned)gx, nblk);
+        if (kernel_name) *kernel_name = w.cin == 32 ? "tconv2_f16_mfma_v3_kernel<2>" : (w.cin == 64 ? "tconv2_f16_mfma_v3_kernel<4>" : "tconv2_f16_mfma_v3_kernel<8>");
+        if (w.cin == 32) hipLaunchKernelGGL(tconv2_f16_mfma_v3_kernel<2>, grid3, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cout, D, H, W, make_fastdiv(W), make_fastdiv(H), make_fastdiv(D));
+        else if (w.cin == 64) hipLaunchKernelGGL(tconv2_f16_mfma_v3_kernel<4>, grid3, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cout, D, H, W, make_fastdiv(W), make_fastdiv(H), make_fastdiv(D));
+        else hipLaunchKernelGGL(tconv2_f16_mfma_v3_kernel<8>, grid3, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cout, D, H, W, make_fastdiv(W), make_fastdiv(H), make_fastdiv(D));
+        MI355_HIP(hipGetLastError());
+        return MI355_OK;
+    }
     if (!v1) {
         dim3 grid2((unsigned)((M + 127) / 128), w.cout / 32);
         hipLaunchKernelGGL(tconv2_f16_mfma_v2_kernel, grid2, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cin, w.cout, D, H,
@@ -437,6 +548,7 @@ int tconv2_mfma_f16(const TConvWeightsH &w, const _Float16 *in, int N, int D, in
         return MI355_OK;
     }
     constexpr int MF = 2;
+    if (kernel_name) *kernel_name = "tconv2_f16_mfma_kernel<2>";
     dim3 grid((unsigned)((M + 4 * MF * 32 - 1) / (4 * MF * 32)), 8 * (w.cout / 32));
     hipLaunchKernelGGL(tconv2_f16_mfma_kernel<MF>, grid, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cin, w.cout, D, H,
                        W, make_fastdiv(W), make_fastdiv(H), make_fastdiv(D));

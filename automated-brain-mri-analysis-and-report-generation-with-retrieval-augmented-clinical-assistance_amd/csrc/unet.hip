@@ -398,7 +398,8 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
             const double vin = (double)N * (Dl / 2) * (Hl / 2) * (Wl / 2);
             ProfScope ps(net, s, f16 ? "tconv2_f16_mfma_v2_kernel" : "tconv2_f32_mfma_v2_kernel", 2.0 * vin * tcin * tcout * 8.0,
                          es * (vin * tcin + 8.0 * vin * tcout + 8.0 * tcin * tcout));
-            if (f16) MI355_TRY(tconv2_mfma_f16(net->tuh[u], (const _Float16 *)cur, N, Dl / 2, Hl / 2, Wl / 2, (_Float16 *)up, s));
+            const char *tname = nullptr;
+            if (f16) { MI355_TRY(tconv2_mfma_f16(net->tuh[u], (const _Float16 *)cur, N, Dl / 2, Hl / 2, Wl / 2, (_Float16 *)up, s, &tname)); ps.rename(tname); }
             else MI355_TRY(tconv2_mfma_f32(net->tu[u], (const float *)cur, N, Dl / 2, Hl / 2, Wl / 2, (float *)up, s));
         }
         // concat order (upsampled, skip): generic_UNet.py:438 - never materialised

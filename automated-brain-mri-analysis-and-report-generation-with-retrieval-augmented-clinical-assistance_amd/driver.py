@@ -258,8 +258,12 @@ def run_both_models(model_dirs, input_folder, output_folder, folds, do_tta, step
             nxt = pool.submit(read_case, prepared[ci + 1][1])  # the next case's gunzip overlaps this case's prediction
         t2 = time.perf_counter()
         data, props = None, None
-        segs = []
-        for mi, model in enumerate(models):
+        segs = [None] * len(models)
+        # (the larger member first: the process-wide activation arena is then allocated once at its final size instead of
+        #  being freed and re-allocated when the second member turns out to need more - a 20-50 GB hipMalloc each time)
+        order = sorted(range(len(models)), key=lambda i: -sum(int(np.prod(v.shape)) for v in models[i].folder.fold_state_dicts[0].values()))
+        for mi in order:
+            model = models[mi]
             if data is None:
                 data, props = preprocessing.preprocess_case(raw, plans=model.folder.plans, spacing_zyx=tuple(reversed(like.zooms)))
                 print(f"Data shape after preprocessing: {tuple(data.shape)}")
@@ -269,7 +273,7 @@ def run_both_models(model_dirs, input_folder, output_folder, folds, do_tta, step
             print(f"Predicting {case_name} with model {mi + 1} ({len(model.nets)} folds)")
             probs = predictor.predict_folds(model.nets, data, model.patch_size, step_size, do_tta, (0, 1, 2), True, model.nonlin)
             lo = [b[0] for b in props["crop_bbox"]]
-            segs.append(ops.regions_to_labels(probs, (1, 2, 3) if model.folder.regions else None, lo, props["original_size_of_raw_data"]))
+            segs[mi] = ops.regions_to_labels(probs, (1, 2, 3) if model.folder.regions else None, lo, props["original_size_of_raw_data"])
         ens = evaluate.convert_labels(ops.label_ensemble(segs[0], segs[1]), label_format)
         torch.cuda.synchronize()
         t3 = time.perf_counter()

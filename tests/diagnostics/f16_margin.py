@@ -3,8 +3,8 @@
 volume (synthetic.make_volume(1000)), models A (seed 7) and B (seed 8), fp16 GPU forward against the CPU oracle forward.
 Prints max / rms logit error, max probability error, label mismatches and the WT/TC/ET Dice.
 
-    python tools/f16_margin.py                  # oracle forwards (cached under gpurun_out/) + the default fp16 path
-    MI355_FUSE_NORM=0 python tools/f16_margin.py --tag separate_norm      # a variant (the switches are read once per process)
+    python tests/diagnostics/f16_margin.py                  # oracle forwards (cached under gpurun_out/) + the default fp16 path
+    MI355_FUSE_NORM=0 python tests/diagnostics/f16_margin.py --tag separate_norm      # a variant (the switches are read once per process)
 """
 import argparse
 import os
@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import brats_amd as amd  # noqa: E402
 from brats_amd import synthetic, preprocessing, ops  # noqa: E402

@@ -184,7 +184,7 @@ F16_EXPECT_KERNEL = {
     (2, 64, 64, 64, 32, 128, 2, 1): "conv3_f16_s2dma_kernel<false>",
     (2, 32, 32, 64, 64, 256, 2, 0): "conv3_f16_s2dma_kernel<false>",
     (6, 24, 40, 48, 16, 128, 2, 1): "conv3_f16_s2dma_kernel<false>",
-    (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f16_mfma_pipe_kernel<1, 2, false, false, 2>",
+    (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f16_mfma_pipe_kernel<1, 2, false, false, 2, false>",
     (8, 8, 8, 8, 320, 320, 1, 1): "conv3_f16_mfma_kernel<1, 2, 2> split-K",
 }
 

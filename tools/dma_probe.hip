@@ -9,6 +9,11 @@
 //   4: lanes 8i .. 8i+7 -> the 128 B of voxel i (64-channel chunk: whole lines)                        8 lines
 //   5: 64 lanes -> 1 KiB contiguous                                                                    8 lines
 //   6: pattern 0 twice in a row on the same voxels (half 0, then half 1): what pairing the planes' pieces buys
+// Channel-blocked tensors (16 B per voxel of a block, x-consecutive voxels contiguous; row pitch 2 KiB = 128 voxels):
+//   7: rows of 10 consecutive voxels (the stride-1 brick: 160 contiguous bytes per row, 6.4 rows per instruction)
+//   8: rows of 17 voxels, EVEN voxels only (16 B at a 32-B stride: the stride-2 kernel's parity-split planar image)
+//   9: rows of 17 voxels, lanes in the order even voxels then odd voxels (all 272 bytes of a row by one instruction, the lane
+//      order permuted within the row)
 // One workgroup of 4 waves per CU, `iters` instructions per wave back to back, vmcnt(8) in flight.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/dma_probe.hip -o tools/dma_probe
 #include <hip/hip_runtime.h>
@@ -26,8 +31,11 @@ __global__ __launch_bounds__(256, 1) void probe(const char *src, unsigned long l
     else if (PATTERN == 2) off = (lane & 31) * 256 + (lane >> 5) * 16;
     else if (PATTERN == 3) off = (lane >> 2) * 256 + (lane & 3) * 16;
     else if (PATTERN == 4) off = (lane >> 3) * 256 + (lane & 7) * 16;
+    else if (PATTERN == 7) off = (lane / 10) * 2048 + (lane % 10) * 16;
+    else if (PATTERN == 8) off = (lane / 9) * 2048 + (lane % 9) * 32;
+    else if (PATTERN == 9) { const int r = lane / 17, c = lane % 17; off = r * 2048 + (c < 9 ? 2 * c : 2 * (c - 9) + 1) * 16; }
     else off = lane * 16;
-    constexpr int SPAN = PATTERN == 0 || PATTERN == 6 ? 64 * 256 : PATTERN == 1 || PATTERN == 2 ? 32 * 256 : PATTERN == 3 ? 16 * 256 : PATTERN == 4 ? 8 * 256 : 1024;
+    constexpr int SPAN = PATTERN >= 7 ? 8 * 2048 : PATTERN == 0 || PATTERN == 6 ? 64 * 256 : PATTERN == 1 || PATTERN == 2 ? 32 * 256 : PATTERN == 3 ? 16 * 256 : PATTERN == 4 ? 8 * 256 : 1024;
     const char *base = src + (size_t)(blockIdx.x * 4 + wave) * window + off;
     char *dst = lds + wave * 1024;
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -82,6 +90,9 @@ int main() {
         run<4>("4: 8 whole lines (8 lanes per voxel)", window);
         run<5>("5: 1 KiB contiguous", window);
         run<6>("6: pattern 0, both halves back to back", window);
+        run<7>("7: blocked layout, rows of 10 voxels x 16 B", window);
+        run<8>("8: blocked layout, rows of 17: even voxels only (32-B stride)", window);
+        run<9>("9: blocked layout, rows of 17: even then odd voxels (permuted)", window);
     }
     return 0;
 }
