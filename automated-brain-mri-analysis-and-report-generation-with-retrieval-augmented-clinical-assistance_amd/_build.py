@@ -21,7 +21,9 @@ from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
-LIB_DIR = PKG_DIR.parent / "lib"
+# the repo keeps the library beside the package (it travels to the GPU box in-tree); an installed copy whose
+# site-packages is read-only points MI355_LIB_DIR somewhere writable
+LIB_DIR = Path(os.environ["MI355_LIB_DIR"]).resolve() if os.environ.get("MI355_LIB_DIR") else PKG_DIR.parent / "lib"
 OBJ_DIR = LIB_DIR / "obj"
 LIB_PATH = LIB_DIR / "libmi355_nnunet.so"
 SOURCES = ["conv3d.hip", "conv3d_f16.hip", "conv3d_f16_s2.hip", "conv_stem.hip", "tconv.hip", "elementwise.hip", "extras.hip", "unet.hip"]

@@ -84,12 +84,12 @@ def load():
         raise Mi355Error(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     if _build.needs_build():
-        # a source or header is newer than the library: rebuild (under the build lock) rather than run stale code
+        # the digest of csrc/ differs from the one the library was built from: rebuild (under the build lock) rather than run stale code
         try:
             _build.build()
         except Exception as e:  # no hipcc on this machine: say so instead of silently running the old library
             import warnings
-            warnings.warn(f"{path} is older than csrc/ and could not be rebuilt ({e}); running the stale library")
+            warnings.warn(f"{path} was built from a different csrc/ and could not be rebuilt ({e}); running the stale library")
     lib = C.CDLL(str(path))
     vp = C.c_void_p
     lib.mi355_last_error.restype = C.c_char_p

@@ -88,11 +88,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // all partial totals are multiples of q, and a double holds multiples of q exactly up to 2^53 q), so the total does not
 // depend on the order: run-to-run and rank-to-rank bit-identical statistics without a second pass.  q scales with the
 // number of voxels V the statistic runs over (2^lv <= V): 2^(lv-40) for sum x, 2^(lv-44) for sum x^2.
-//   * What the rounding costs: a workgroup's partial covers >= 128 voxels, so there are at most V / 128
-//     partials and the worst case - every partial off by q / 2 in the same direction - moves mean x by q / 256 = 2^(lv-48)
-//     and mean x^2 by 2^(lv-52): 7.5e-9 and 4.7e-10 at a 128^3 patch (lv = 21), nothing against eps = 1e-5 however small
-//     the channel's pre-norm rms is (round 2's quantum for sum x^2, 2^(lv-30) = 2e-3 at that patch, zeroed the variance
-//     of a channel with rms 1e-3: every partial rounded to 0).
+//   * What the rounding costs: a partial (one wave's or one workgroup's share of a channel) covers >= 32 voxels,
+//     so there are at most V / 32 partials and the worst case - every partial off by q / 2 in the same direction - moves
+//     mean x by q / 64 = 2^(lv-46) and mean x^2 by 2^(lv-50): 3.0e-8 and 1.9e-9 at a 128^3 patch (lv = 21), nothing against
+//     eps = 1e-5 however small the channel's pre-norm rms is (round 2's quantum for sum x^2, 2^(lv-30) = 2e-3 at that patch,
+//     zeroed the variance of a channel with rms 1e-3: every partial rounded to 0).
 //   * Where the additions stay exact (all totals below 2^53 q): |mean x| < 8192 and rms x < 16.  Beyond those
 //     magnitudes the additions merely stop being exact: the statistics stay correct to fp64 rounding, only the order
 //     independence is lost.
@@ -100,6 +100,67 @@ __device__ __forceinline__ double quantise_partial(double v, int k, long voxels)
     const int lv = 63 - __clzll((unsigned long long)(voxels > 0 ? voxels : 1));
     const int e = lv - (k == 0 ? 40 : 44);
     return ldexp(rint(ldexp(v, -e)), e);
+}
+
+// Sum over the 32 lanes of a wave half (lanes 0-31 / 32-63), returned in every lane of that half.  Four DPP steps (quad_perm,
+// quad_perm, row_half_mirror, row_mirror: plain VALU adds with a lane-permuted operand, 4 cycles each) give every lane of a
+// 16-lane row its row total; one cross-row exchange finishes.  Round 3: the Instance/GroupNorm statistics epilogues used a
+// five-step __shfl_xor butterfly per value - hipcc lowers every step to ds_swizzle / ds_bpermute, i.e. an LDS round trip,
+// and 640 of them in dependent chains cost the fp16 LDS-DMA kernel 16.6k cycles per tile (20.2k against 3.5k for the
+// epilogue without statistics, tools/h16_probe.hip stamps: 31 % of a 4-chunk tile).
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));  // (bound_ctrl: no 'old' operand to materialise)
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_perm<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_perm<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_perm<0x141>(v);  // row_half_mirror: lane <-> 7 - lane within 8: the other quad's total
+    v += dpp_perm<0x140>(v);  // row_mirror: lane <-> 15 - lane within 16: the other half-row's total
+    return v;
+}
+__device__ __forceinline__ float half32_sum(float v) {
+    v = row16_sum(v);
+    return v + __shfl_xor(v, 16);
+}
+
+// Transposing reduction of the statistics of a 32x32 accumulator fragment whose LANES are voxels (lane & 31) and whose 16
+// registers are channels: a lane holds 16 partial sums (s1) and 16 partial sums of squares (s2), and the totals over the 32
+// lanes of its half-wave are wanted.  Reducing each of the 32 values with a butterfly is 32 x 5 cross-lane additions per
+// lane (the compiler made 768 VALU instructions of them, h16 stamps: +6.1k cycles per tile).  Here every step HALVES the
+// values a lane still carries: the two partners keep one half each and send the other, so the steps cost 16+8+4+2+1 = 31
+// additions, and each of the 32 lanes ends with the total of exactly ONE value - the one it then adds to the statistics
+// buffer, with no trip through LDS:
+//   index r = (lane >> 1 & 1) + 2 (lane & 1) + 4 (lane >> 2 & 1) + 8 (lane >> 3 & 1) of s1 (lane & 16 == 0) or s2 (lane & 16)
+// Step 1 is gfx950's v_permlane16_swap (rows 1 and 3 of the first operand change places with rows 0 and 2 of the second:
+// one instruction is the exchange of both directions); the 16-lane rows then use DPP.  The half-mirror step comes before
+// the two quad steps because its partner (lane ^ 7) differs in the quad bits too: the later partners (lane ^ 1, lane ^ 2)
+// have made the same choice in it, which is all a halving step needs.
+__device__ __forceinline__ int stat_slot_r(int lane) { return ((lane >> 1) & 1) + 2 * (lane & 1) + (lane & 12); }
+typedef float stat_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float half32_reduce_scatter(const stat_f32x2 (&s1)[8], const stat_f32x2 (&s2)[8], int lane) {
+    // (inline asm: hipcc 7.2 miscompiles __builtin_amdgcn_permlane16_swap - both members of the returned pair come out as the
+    //  same register, tools/stat_probe.hip.  The hazard recogniser does not look into inline asm: the s_nop 1 in front covers
+    //  the two wait states a VALU write needs before a permlane reads the register, the one behind covers its readers.)
+    float y[16];
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) {
+        float a0 = s1[(q >> 1)][0], a1 = s1[(q >> 1)][1], a2 = s1[(q >> 1) + 1][0], a3 = s1[(q >> 1) + 1][1];
+        float c0 = s2[(q >> 1)][0], c1 = s2[(q >> 1)][1], c2 = s2[(q >> 1) + 1][0], c3 = s2[(q >> 1) + 1][1];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                     "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+        y[q] = a0 + c0; y[q + 1] = a1 + c1; y[q + 2] = a2 + c2; y[q + 3] = a3 + c3;
+    }
+    const bool b3 = lane & 8, b2 = lane & 4, b0 = lane & 1, b1 = lane & 2;
+    float z[8], w[4], u[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (b3 ? y[i + 8] : y[i]) + dpp_perm<0x128>(b3 ? y[i] : y[i + 8]);  // row_ror:8 = lane ^ 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (b2 ? z[i + 4] : z[i]) + dpp_perm<0x141>(b2 ? z[i] : z[i + 4]);  // row_half_mirror = lane ^ 7
+#pragma unroll
+    for (int i = 0; i < 2; ++i) u[i] = (b0 ? w[i + 2] : w[i]) + dpp_perm<0xB1>(b0 ? w[i] : w[i + 2]);   // lane ^ 1
+    return (b1 ? u[1] : u[0]) + dpp_perm<0x4E>(b1 ? u[0] : u[1]);                                      // lane ^ 2
 }
 
 // fp16 activation layout (round 3): channel-blocked NDHWC, [N][C / 8][D][H][W][8] ("B8", oneDNN's nCdhw8c).  A voxel's eight

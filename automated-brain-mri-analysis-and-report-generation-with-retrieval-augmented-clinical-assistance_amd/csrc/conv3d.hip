@@ -138,16 +138,18 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
         }
         return;
     }
-    float s1[NF][16], s2[NF][16];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 s1[NF][8], s2[NF][8];
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s1[nf][r] = 0.f; s2[nf][r] = 0.f; }
+        for (int r = 0; r < 8; ++r) { s1[nf][r] = f32x2{0.f, 0.f}; s2[nf][r] = f32x2{0.f, 0.f}; }
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         const int v = (wave * MF + mf) * 32 + l31;
         const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
         const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
+        const float in = ok ? 1.f : 0.f;  // a voxel beyond a ragged edge adds nothing to the statistics
         float *orow = p.out + ((((size_t)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * p.Cout + co_blk + 4 * half;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
@@ -160,35 +162,27 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
                     float x = acc[mf][nf][4 * g + k] + bias[k];
                     if (p.act == ACT_LRELU) x = x > 0.f ? x : x * p.slope;
                     val[k] = x;
-                    if (ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {  // v_pk_add_f32 / v_pk_fma_f32: one instruction per value pair
+                    const f32x2 m = f32x2{val[k], val[k + 1]} * f32x2{in, in};
+                    s1[nf][2 * g + (k >> 1)] += m;
+                    s2[nf][2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[nf][2 * g + (k >> 1)]);
                 }
                 if (ok) *(f32x4 *)(orow + nf * 32 + 8 * g) = val;
             }
         }
     }
-    {
-        if (sync_before_red) __syncthreads();
+    // (round 3) transposing reduction over the 32 voxel lanes (common.h): each lane ends with the total of ONE (cout, statistic)
+    // of this wave's MF * 32 voxels and adds it itself - no LDS, no barrier (round 2: 32 NF butterflies, a cross-wave reduction
+    // through `red` behind two __syncthreads()).  Quantised partials: exact additions, hence order-independent.
+    (void)red; (void)sync_before_red; (void)tid;
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float a = s1[nf][r], b = s2[nf][r];
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-                if (l31 == 0) {
-                    const int c = nf * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    red[(wave * NF * 32 + c) * 2 + 0] = a;
-                    red[(wave * NF * 32 + c) * 2 + 1] = b;
-                }
-            }
-        __syncthreads();
-        if (tid < NF * 32 * 2) {
-            const int c = tid >> 1, k = tid & 1;
-            double tot = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
-            atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, quantise_partial(tot, k, (long)p.Do * p.Ho * p.Wo));  // exact, hence order-independent (common.h)
-        }
+    for (int nf = 0; nf < NF; ++nf) {
+        const float tot = half32_reduce_scatter(s1[nf], s2[nf], lane);
+        const int r = stat_slot_r(lane), k = (lane >> 4) & 1;
+        const int c = nf * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, quantise_partial((double)tot, k, (long)p.Do * p.Ho * p.Wo));
     }
 }
 

@@ -182,16 +182,18 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
         }
         return;
     }
-    float s1[NF][16], s2[NF][16];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 s1[NF][8], s2[NF][8];
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s1[nf][r] = 0.f; s2[nf][r] = 0.f; }
+        for (int r = 0; r < 8; ++r) { s1[nf][r] = f32x2{0.f, 0.f}; s2[nf][r] = f32x2{0.f, 0.f}; }
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         const int v = (wave * MF + mf) * 32 + l31;
         const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
         const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
+        const float in = ok ? 1.f : 0.f;  // a voxel beyond a ragged edge adds nothing
         const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
         half_t *orow = p.out + (((size_t)n * (p.Cout >> 3) + (co_blk >> 3)) * Vo + ((size_t)oz * p.Ho + oy) * p.Wo + ox) * 8 + 4 * half;
 #pragma unroll
@@ -200,36 +202,27 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
             for (int g = 0; g < 4; ++g) {
                 f16x4 val;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float x = acc[mf][nf][4 * g + k];
-                    x = fmaxf(x, x * slope);
-                    val[k] = (half_t)x;
-                    if (ok) { s1[nf][4 * g + k] += x; s2[nf][4 * g + k] += x * x; }
+                for (int k = 0; k < 4; k += 2) {
+                    f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
+                    if (lrelu) x = f32x2{fmaxf(x[0], x[0] * slope), fmaxf(x[1], x[1] * slope)};  // (wave-uniform; conv -> norm -> LeakyReLU has none here)
+                    val[k] = (half_t)x[0];
+                    val[k + 1] = (half_t)x[1];
+                    const f32x2 m = x * f32x2{in, in};
+                    s1[nf][2 * g + (k >> 1)] += m;  // v_pk_add_f32 / v_pk_fma_f32: one instruction per value pair
+                    s2[nf][2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[nf][2 * g + (k >> 1)]);
                 }
                 if (ok) store_f16x4<SC1>(orow + (size_t)(nf * 4 + g) * Vo * 8, val);
             }
         }
     }
+    // (round 3) transposing reduction over the 32 voxel lanes (common.h): every lane ends with the total of ONE (cout, statistic)
+    // of this wave's MF * 32 voxels and adds it itself - no LDS, no barrier.  Quantised partials: exact additions in any order.
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a = s1[nf][r], b = s2[nf][r];
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-            if (l31 == 0) {
-                const int c = nf * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                red[(wave * NF * 32 + c) * 2 + 0] = a;
-                red[(wave * NF * 32 + c) * 2 + 1] = b;
-            }
-        }
-    __syncthreads();
-    if (tid < NF * 32 * 2) {
-        const int c = tid >> 1, k = tid & 1;
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
-        atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, quantise_partial(tot, k, (long)p.Do * p.Ho * p.Wo));  // exact, hence order-independent (common.h)
+    for (int nf = 0; nf < NF; ++nf) {
+        const float tot = half32_reduce_scatter(s1[nf], s2[nf], lane);
+        const int r = stat_slot_r(lane), k = (lane >> 4) & 1;
+        const int c = nf * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, quantise_partial((double)tot, k, (long)p.Do * p.Ho * p.Wo));
     }
 }
 
@@ -467,9 +460,9 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
                            (STRIDE * (tc.ox0 + (1 << p.lx) - 1) + 1 > p.Wi));
     };
     const int dst0 = (tid & 1) * p.plane_bytes + (tid >> 1) * 16;  // LDS byte offset of slot 0; slot r is 128 voxels further
-    // Slots beyond the brick (and every slot when there is no next chunk) are written to a junk area of 16 B per thread
-    // instead of being predicated: a predicated ds_write is an exec-mask branch per slot in the tap loop (round 3)
-    const int junk_dst = 2 * buf_bytes + 4 * NF * 32 * 2 * (int)sizeof(float) + tid * 16;
+    // (tried in round 3 and dropped: a 4-KiB junk area so that slots beyond the brick are written unconditionally instead of
+    //  behind an exec-mask branch - the extra LDS pushed the 512-voxel-tile kernels from two workgroups per CU to one,
+    //  1018 -> 826 TFLOP/s)
     auto stage_issue = [&](const TileCoord &tc, int faces, bool ragged, int ch, int r) {
         const int cglob = ch * 16;
         const half_t *src; int Csrc, coff;
@@ -573,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = in ? v[j] : 0.f;
             }
-            *(f32x4 *)(lds_raw + (slot_valid(r) ? dst0 + r * 2048 : junk_dst)) = v;
+            if (slot_valid(r)) *(f32x4 *)(lds_raw + dst0 + r * 2048) = v;
         }
     }
     f16x8 bq[BD][NF];
@@ -656,11 +649,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
 #pragma unroll
                         for (int j = 0; j < 4; ++j) st_v[r][j] = in ? st_v[r][j] : 0.f;
                     }
-                    {
-                        int dsel = (have_next && slot_valid(r)) ? (buf ^ 1) * buf_bytes + dst0 + r * 2048 : junk_dst;
-                        asm volatile("" : "+v"(dsel));  // (a select, not a branch)
-                        *(f32x4 *)(lds_raw + dsel) = st_v[r];
-                    }
+                    if (have_next && slot_valid(r)) *(f32x4 *)(bufn + dst0 + r * 2048) = st_v[r];
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -1084,51 +1073,60 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
             unsigned wr = img + l31 * G::EPI_PITCH + half * 8;
             asm volatile("" : "+v"(wr));
             // (cout fragment outermost: the statistics of one fragment are 32 live registers, not 64)
-            static_for<0, NF>([&](auto nf_c) {
-                constexpr int nf = decltype(nf_c)::value;
-                float s1[16], s2[16];
-                if constexpr (STATS) {
+            // A statistics epilogue usually follows a convolution WITHOUT activation (conv -> norm -> LeakyReLU): that case
+            // skips the 3 VALU instructions per value pair of max(x, slope x) - a wave-uniform choice of two instantiations.
+            auto transpose_out = [&](auto act_c) {
+                constexpr bool ACT = decltype(act_c)::value;
+                static_for<0, NF>([&](auto nf_c) {
+                    constexpr int nf = decltype(nf_c)::value;
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 s1[8], s2[8];
+                    if constexpr (STATS) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-                }
+                        for (int r = 0; r < 8; ++r) { s1[r] = f32x2{0.f, 0.f}; s2[r] = f32x2{0.f, 0.f}; }
+                    }
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf)
+                    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        typedef float f32x2 __attribute__((ext_vector_type(2)));
-                        const f32x2 slope2 = {slope, slope};
-                        f16x4 val;
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x2 slope2 = {slope, slope};
+                            f16x4 val;
 #pragma unroll
-                        for (int k = 0; k < 4; k += 2) {
-                            const f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
-                            f32x2 y;
-                            float m0, m1;
-                            asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
-                            asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(x[0]), "v"(y[0]));
-                            asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(x[1]), "v"(y[1]));
-                            val[k] = (half_t)m0;
-                            val[k + 1] = (half_t)m1;
-                            if constexpr (STATS) {
-                                s1[4 * g + k] += m0; s2[4 * g + k] += m0 * m0;
-                                s1[4 * g + k + 1] += m1; s2[4 * g + k + 1] += m1 * m1;
+                            for (int k = 0; k < 4; k += 2) {
+                                const f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
+                                f32x2 m = x;
+                                if constexpr (ACT) {
+                                    f32x2 y;
+                                    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(x[0]), "v"(y[0]));
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(x[1]), "v"(y[1]));
+                                }
+                                val[k] = (half_t)m[0];
+                                val[k + 1] = (half_t)m[1];
+                                if constexpr (STATS) {  // v_pk_add_f32 + v_pk_fma_f32: one instruction each per value PAIR
+                                    s1[2 * g + (k >> 1)] += m;
+                                    s2[2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[2 * g + (k >> 1)]);
+                                }
                             }
+                            *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + (nf * 32 + 8 * g) * 2) = val;
                         }
-                        *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + (nf * 32 + 8 * g) * 2) = val;
+                    if constexpr (STATS) {
+                        // (round 3) transposing reduction, common.h: every lane ends with ONE total over the 32 voxel lanes of its
+                        // half-wave (x 4 fragments = this wave's 128 voxels) and adds it itself - no LDS, no barrier; round 2
+                        // reduced 32 values with butterflies, crossed the four waves through LDS and two __syncthreads().
+                        // Quantised partials: exact additions in any order (common.h).
+                        const float tot = half32_reduce_scatter(s1, s2, lane);
+                        const int r = stat_slot_r(lane), k = (lane >> 4) & 1;
+                        const int c = nf * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                        atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co_blk + c) * 2 + k, quantise_partial((double)tot, k, (long)p.Do * p.Ho * p.Wo));
                     }
-                if constexpr (STATS) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float a = s1[r], b = s2[r];
-#pragma unroll
-                        for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-                        if (l31 == 0) {
-                            const int c = nf * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            red[(wave * NF * 32 + c) * 2 + 0] = a;
-                            red[(wave * NF * 32 + c) * 2 + 1] = b;
-                        }
-                    }
-                }
-            });
+                });
+            };
+            if constexpr (STATS) {
+                if (p.act == ACT_LRELU) transpose_out(std::true_type{}); else transpose_out(std::false_type{});
+            } else {
+                transpose_out(std::true_type{});
+            }
             // rows 8 j .. 8 j + 7 of the image are the x-row (z = 2 wave + (j >> 3), y = j & 7) of the tile: 8 voxels x 8 cout blocks.
             // Blocked output: lane -> (block lane >> 3, voxel x = lane & 7): 8 lanes write the 128 contiguous bytes of a block's
             // x-row, a store instruction eight whole lines
@@ -1150,17 +1148,6 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                 if constexpr (MI355_H16_SC1 != 0) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(lo), "v"(v), "s"(row) : "memory");
                 else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(lo), "v"(v), "s"(row) : "memory");
             });
-            if constexpr (STATS) {
-                __syncthreads();
-                if (tid < NF * 32 * 2) {
-                    const int c = tid >> 1, k = tid & 1;
-                    double tot = 0.0;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) tot += (double)red[(w * NF * 32 + c) * 2 + k];
-                    atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co_blk + c) * 2 + k, quantise_partial(tot, k, (long)p.Do * p.Ho * p.Wo));  // exact, hence order-independent (common.h)
-                }
-                __syncthreads();  // (red is written again by the next tile)
-            }
         }
         cur = nxt_tile;
         H16_T(t_e1);
@@ -1396,7 +1383,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         MI355_REQUIRE((long)a.IZ * c.Hi * c.Wi < (1l << 24) && ((long)a.IZ * c.Hi * c.Wi + (long)c.Di * c.Hi * c.Wi) * 16 < (1l << 31),
                       "volume too large for the 32-bit staging offsets");
         a.total_tiles = (int)tiles;
-        const size_t lds_bytes = (size_t)4 * a.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float) + 256 * 16;  // bricks, statistics, junk slots
+        const size_t lds_bytes = (size_t)4 * a.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float);
         MI355_REQUIRE(lds_bytes <= 160 * 1024, "conv brick needs %zu B of LDS", lds_bytes);
         int gx = 512 / gy;
         gx = gx < 8 ? 8 : (gx / 8) * 8;
@@ -1445,7 +1432,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         ConvArgsH b = a;
         fill_geometry_h(b, 2, 128);
         const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
-        const size_t lds_bytes = (size_t)4 * b.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float) + 256 * 16;
+        const size_t lds_bytes = (size_t)4 * b.plane_bytes + 4 * w.nf * 32 * 2 * sizeof(float);
         if (s2pipe && tiles * gy >= 768 && tiles < (1l << 30) && b.IX * b.IY * b.IZ <= 13 * 128 && lds_bytes <= 160 * 1024 &&
             (long)b.IZ * c.Hi * c.Wi < (1l << 24) && ((long)b.IZ * c.Hi * c.Wi + (long)c.Di * c.Hi * c.Wi) * 16 < (1l << 31) && !c.in_scale) {
             b.total_tiles = (int)tiles;

@@ -255,10 +255,12 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
             const unsigned img = (unsigned)(size_t)(lds_char *)(lds_raw + G::EPI_OFF) + wave * G::EPI_WAVE_BYTES;
             unsigned wr = img + l31 * G::EPI_PITCH + half * 8;
             asm volatile("" : "+v"(wr));
-            float s1[16], s2[16];
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const bool lrelu = p.act == ACT_LRELU;
+            f32x2 s1[8], s2[8];
             if constexpr (STATS) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+                for (int r = 0; r < 8; ++r) { s1[r] = f32x2{0.f, 0.f}; s2[r] = f32x2{0.f, 0.f}; }
             }
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
@@ -266,28 +268,26 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
                 for (int g = 0; g < 4; ++g) {
                     f16x4 val;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float x = acc[mf][4 * g + k];
-                        const float m = fmaxf(x, x * slope);
-                        val[k] = (half_t)m;
-                        if constexpr (STATS) { s1[4 * g + k] += m; s2[4 * g + k] += m * m; }
+                    for (int k = 0; k < 4; k += 2) {
+                        f32x2 m = {acc[mf][4 * g + k], acc[mf][4 * g + k + 1]};
+                        if (lrelu) m = f32x2{fmaxf(m[0], m[0] * slope), fmaxf(m[1], m[1] * slope)};  // (wave-uniform)
+                        val[k] = (half_t)m[0];
+                        val[k + 1] = (half_t)m[1];
+                        if constexpr (STATS) {  // v_pk_add_f32 / v_pk_fma_f32: one instruction per value pair
+                            s1[2 * g + (k >> 1)] += m;
+                            s2[2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[2 * g + (k >> 1)]);
+                        }
                     }
                     // row = voxel mf * 32 + l31, couts 8 g + 4 half .. + 3 of the wave's 32
                     *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + g * 16) = val;
                 }
             if constexpr (STATS) {
-                float *red = (float *)(lds_raw + G::RED_OFF) + wave * 64;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float sa = s1[r], sb = s2[r];
-#pragma unroll
-                    for (int m = 1; m < 32; m <<= 1) { sa += __shfl_xor(sa, m); sb += __shfl_xor(sb, m); }
-                    if (l31 == 0) {
-                        const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        red[c * 2 + 0] = sa;
-                        red[c * 2 + 1] = sb;
-                    }
-                }
+                // transposing reduction over the 32 voxel lanes (common.h): each lane ends with the total of one (cout, statistic)
+                // of the tile's 128 voxels and adds it itself; quantised partials: exact, hence order-independent
+                const float tot = half32_reduce_scatter(s1, s2, lane);
+                const int r = stat_slot_r(lane), k = (lane >> 4) & 1;
+                const int c = 8 * (r >> 2) + 4 * half + (r & 3);
+                atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co_blk + wave * 32 + c) * 2 + k, quantise_partial((double)tot, k, (long)p.Do * p.Ho * p.Wo));
             }
             // image rows 16 j .. 16 j + 15 = output voxels (z = j >> 1, y = 2 (j & 1) + yy, x), yy = 0, 1.  Blocked output (common.h):
             // lane -> (cout block lane >> 4 of the wave's four, yy = (lane >> 3) & 1, x = lane & 7): eight lanes write the 128
@@ -305,15 +305,6 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
                 // sc1: nothing on this XCD reads the output again; kept in its L2 the lines would evict brick lines
                 asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(lo2), "v"(v), "s"(rowp) : "memory");
             });
-            if constexpr (STATS) {
-                // (wave-private: the 64 sums above were written by lanes 0 and 32 of this wave; LDS operations of one wave
-                //  complete in order, the compiler's lgkmcnt wait before the read is all it takes)
-                const float *red = (const float *)(lds_raw + G::RED_OFF) + wave * 64;
-                const int c = lane >> 1, k = lane & 1;
-                const double tot = (double)red[c * 2 + k];
-                atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co_blk + wave * 32 + c) * 2 + k,
-                          quantise_partial(tot, k, (long)p.Do * p.Ho * p.Wo));  // exact, hence order-independent (common.h)
-            }
         }
         cur = nxt_tile;
     }

@@ -96,9 +96,10 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
     const bool do_stats = STATS < 0 ? p.stats != nullptr : STATS != 0;
     typedef StemEpi<T> E;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    float s1[16], s2[16];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 s1[8], s2[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    for (int r = 0; r < 8; ++r) { s1[r] = f32x2{0.f, 0.f}; s2[r] = f32x2{0.f, 0.f}; }
     const float slope = p.act == ACT_LRELU ? p.slope : 1.0f;
     char *img = img_all + wave * E::WAVE_BYTES;
     f32x4 bias[4];
@@ -109,6 +110,7 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
     for (int mf = 0; mf < 4; ++mf) {
         const int oy = oy0 + mf;
         const bool ok = (oz < p.D) && (oy < p.H) && (ox0 + l31 < p.W);
+        const float in = ok ? 1.f : 0.f;  // a voxel beyond a ragged edge adds nothing to the statistics
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 val;
@@ -117,7 +119,14 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
                 float x = acc[mf][4 * g + k] + bias[g][k];
                 x = fmaxf(x, x * slope);
                 val[k] = x;
-                if (do_stats && ok) { s1[4 * g + k] += x; s2[4 * g + k] += x * x; }
+            }
+            if (do_stats) {  // v_pk_add_f32 / v_pk_fma_f32: one instruction per value pair
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {
+                    const f32x2 m = f32x2{val[k], val[k + 1]} * f32x2{in, in};
+                    s1[2 * g + (k >> 1)] += m;
+                    s2[2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[2 * g + (k >> 1)]);
+                }
             }
             char *dst = img + l31 * E::PITCH + (8 * g + 4 * half) * (int)sizeof(T);
             if (sizeof(T) == 4) *(f32x4 *)dst = val;
@@ -151,26 +160,13 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
         }
     }
     if (do_stats) {
-        __syncthreads();  // the brick is dead: reuse it for the cross-wave reduction
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a = s1[r], b = s2[r];
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-            if (l31 == 0) {
-                const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-                red[(wave * 32 + c) * 2 + 0] = a;
-                red[(wave * 32 + c) * 2 + 1] = b;
-            }
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int c = tid >> 1, k = tid & 1;
-            double tot = 0.0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) tot += (double)red[(w * 32 + c) * 2 + k];
-            atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, quantise_partial(tot, k, (long)p.D * p.H * p.W));  // exact, hence order-independent (common.h)
-        }
+        // (round 3) transposing reduction over the 32 voxel lanes (common.h): each lane ends with the total of one (cout,
+        // statistic) over this wave's 128 voxels and adds it itself - no LDS, no barrier (round 2: 32 butterflies, a cross-wave
+        // reduction through the dead brick behind two __syncthreads()).  Quantised partials: exact, hence order-independent.
+        const float tot = half32_reduce_scatter(s1, s2, lane);
+        const int r = stat_slot_r(lane), k = (lane >> 4) & 1;
+        const int c = 8 * (r >> 2) + 4 * half + (r & 3);
+        atomicAdd(p.stats + ((size_t)n * p.Cout + co_blk + c) * 2 + k, quantise_partial((double)tot, k, (long)p.D * p.H * p.W));
     }
 }
 

@@ -362,7 +362,10 @@ struct MirrorList {
 //   result = sum_m  mult * flip_back(nonlin(net(flip_m(x))))      mult = 1/n_mirrors, m in list order
 //   result *= gaussian ; aggregated[:, tile] += result ; normaliser[tile] += gaussian
 // feat holds the last decoder feature map of the n_mirrors forwards of this tile.
-template <typename T, bool NORM>
+// NM: compile-time mirror count (8 = the reference's full TTA; 0 = run time).  With the loop unrolled the feature loads of all
+// mirrors are independent of the sigmoid / softmax arithmetic between them and go out together: this kernel is a stream
+// of 16-B loads (32 per voxel for 32 channels x 8 mirrors), and as a run-time loop it had one mirror's four in flight.
+template <typename T, bool NORM, int NM = 0>
 __global__ void head_aggregate_kernel(const T *feat, const float *w, const float *b, int C, int ncls,
                                       MirrorList ml, int P0, int P1, int P2, int nonlin, const float *gauss,
                                       float *agg, float *cnt, int Zp, int Yp, int Xp, int z0, int y0, int x0, FeatNorm fn) {
@@ -376,7 +379,10 @@ __global__ void head_aggregate_kernel(const T *feat, const float *w, const float
         float res[HEAD_MAX_CLS];
 #pragma unroll
         for (int k = 0; k < HEAD_MAX_CLS; ++k) res[k] = 0.f;
-        for (int mi = 0; mi < ml.n; ++mi) {
+        const int nm = NM ? NM : ml.n;
+#pragma unroll
+        for (int mi = 0; mi < (NM ? NM : 8); ++mi) {
+            if (!NM && mi >= nm) break;
             const int m = ml.m[mi];
             const int sz = (m & 1) ? P0 - 1 - pz : pz;
             const int sy = (m & 2) ? P1 - 1 - py : py;
@@ -418,12 +424,11 @@ static void launch_head_aggregate(const HeadWeights &w, const T *feat, const Mir
     const int64_t PV = (int64_t)P0 * P1 * P2;
     int64_t blocks = (PV + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    if (fn.scale)
-        hipLaunchKernelGGL((head_aggregate_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, feat, w.w_dev, w.b_dev, w.cin,
-                           w.ncls, ml, P0, P1, P2, nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0, fn);
-    else
-        hipLaunchKernelGGL((head_aggregate_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, feat, w.w_dev, w.b_dev, w.cin,
-                           w.ncls, ml, P0, P1, P2, nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0, fn);
+#define MI355_HA_LAUNCH(NORM_, NM_) hipLaunchKernelGGL((head_aggregate_kernel<T, NORM_, NM_>), dim3((unsigned)blocks), dim3(256), 0, s, feat, w.w_dev, w.b_dev, \
+                                                      w.cin, w.ncls, ml, P0, P1, P2, nonlin, gauss, agg, cnt, Zp, Yp, Xp, z0, y0, x0, fn)
+    if (fn.scale) { if (ml.n == 8) MI355_HA_LAUNCH(true, 8); else MI355_HA_LAUNCH(true, 0); }
+    else { if (ml.n == 8) MI355_HA_LAUNCH(false, 8); else MI355_HA_LAUNCH(false, 0); }
+#undef MI355_HA_LAUNCH
 }
 
 int head_aggregate(const HeadWeights &w, const void *feat, int dtype, int first_sample, const int *mirrors_host,

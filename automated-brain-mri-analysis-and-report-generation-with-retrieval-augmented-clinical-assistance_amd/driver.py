@@ -249,41 +249,61 @@ def run_both_models(model_dirs, input_folder, output_folder, folds, do_tta, step
     for o in outs:
         o.mkdir(parents=True, exist_ok=True)
     writes, finals = [], []
+    # Two streams (the one documented exception to "one stream at a time"): the NEXT case's host-to-device
+    # copy, crop mask and z-score run on `side` while the current case's forwards run on the main stream.  Preprocessing
+    # and prediction use disjoint scratch slots of the library (crop / z-score vs arena / aggregation), and the hand-off is
+    # an event: the main stream waits for the case's preprocessing before its first tile gather.
+    main_stream = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+
+    def preprocess_on_side(raw, like, plans):
+        with torch.cuda.stream(side):
+            data, props = preprocessing.preprocess_case(raw, plans=plans, spacing_zyx=tuple(reversed(like.zooms)))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        data.record_stream(main_stream)
+        return data, props, ev
+
+    plans0 = models[0].folder.plans
     nxt = pool.submit(read_case, prepared[0][1])
+    raw, like = nxt.result()
+    ready = preprocess_on_side(raw, like, plans0)
     for ci, (case_name, case_files) in enumerate(prepared):
         print(f"\n{'=' * 70}\nProcessing case: {case_name}\n{'=' * 70}")
         t1 = time.perf_counter()
-        raw, like = nxt.result()
         if ci + 1 < len(prepared):
             nxt = pool.submit(read_case, prepared[ci + 1][1])  # the next case's gunzip overlaps this case's prediction
+        data, props, ev = ready
+        cur_raw_channels, cur_like = raw.shape[0], like
+        main_stream.wait_event(ev)
+        print(f"Data shape after preprocessing: {tuple(data.shape)}")
         t2 = time.perf_counter()
-        data, props = None, None
         segs = [None] * len(models)
         # (the larger member first: the process-wide activation arena is then allocated once at its final size instead of
         #  being freed and re-allocated when the second member turns out to need more - a 20-50 GB hipMalloc each time)
         order = sorted(range(len(models)), key=lambda i: -sum(int(np.prod(v.shape)) for v in models[i].folder.fold_state_dicts[0].values()))
         for mi in order:
             model = models[mi]
-            if data is None:
-                data, props = preprocessing.preprocess_case(raw, plans=model.folder.plans, spacing_zyx=tuple(reversed(like.zooms)))
-                print(f"Data shape after preprocessing: {tuple(data.shape)}")
-            else:
-                preprocessing.check_plans(model.folder.plans, raw.shape[0])
-                preprocessing.check_spacing(model.folder.plans, tuple(reversed(like.zooms)), data.shape[1:])
+            if model.folder.plans is not plans0:
+                preprocessing.check_plans(model.folder.plans, cur_raw_channels)
+                preprocessing.check_spacing(model.folder.plans, tuple(reversed(cur_like.zooms)), data.shape[1:])
             print(f"Predicting {case_name} with model {mi + 1} ({len(model.nets)} folds)")
             probs = predictor.predict_folds(model.nets, data, model.patch_size, step_size, do_tta, (0, 1, 2), True, model.nonlin)
             lo = [b[0] for b in props["crop_bbox"]]
             segs[mi] = ops.regions_to_labels(probs, (1, 2, 3) if model.folder.regions else None, lo, props["original_size_of_raw_data"])
         ens = evaluate.convert_labels(ops.label_ensemble(segs[0], segs[1]), label_format)
+        if ci + 1 < len(prepared):  # the forwards above are only enqueued: preprocess the next case beside them
+            raw, like = nxt.result()
+            ready = preprocess_on_side(raw, like, plans0)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         host = [t.cpu().numpy() for t in (segs[0], segs[1], ens)]
         final_output = output_folder / f"{case_name}.nii.gz"
         for arr, path in zip(host, (outs[0] / f"{case_name}.nii.gz", outs[1] / f"{case_name}.nii.gz", final_output)):
             # label volumes are written (x, y, z); the reference's ensemble saves with seg1's header = the input geometry
-            writes.append(pool.submit(nifti.save_like, path, np.ascontiguousarray(arr.transpose(2, 1, 0)), like))
-        v = volumes_of(host[2], like.zooms)
-        print(f"[OK] Completed: {final_output}  (read {t2 - t1:.2f} s, preprocess + predict {t3 - t2:.2f} s)")
+            writes.append(pool.submit(nifti.save_like, path, np.ascontiguousarray(arr.transpose(2, 1, 0)), cur_like))
+        v = volumes_of(host[2], cur_like.zooms)
+        print(f"[OK] Completed: {final_output}  (wait for input {t2 - t1:.2f} s, predict {t3 - t2:.2f} s)")
         print(f"\nTumor Volume Analysis for {case_name}:")
         print(f"  NCR (Necrotic Core):        {v['NCR']:.2f} cm3")
         print(f"  ED (Peritumoral Edema):     {v['ED']:.2f} cm3")

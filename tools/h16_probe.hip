@@ -17,7 +17,7 @@ int device_scratch(int slot, size_t bytes, void **out, bool zeroed) {
 }  // namespace mi355
 using namespace mi355;
 
-static int run(int N, int D, int cin, int cout, int reps) {
+static int run(int N, int D, int cin, int cout, int reps, bool inaff = false, bool stats = false) {
     const size_t vin = (size_t)N * D * D * D;
     std::vector<_Float16> x(vin * cin);
     std::vector<float> w((size_t)cout * cin * 27), b(cout);
@@ -33,6 +33,16 @@ static int run(int N, int D, int cin, int cout, int reps) {
     if (conv_weights_upload_f16(w.data(), b.data(), cin, cin, cout, 1, &cw) != MI355_OK) return 1;
     ConvCallH c;
     c.in0 = xd; c.C0 = cin; c.N = N; c.Di = D; c.Hi = D; c.Wi = D; c.out = yd; c.act = ACT_LRELU; c.slope = 0.01f;
+    float *sc = nullptr, *sh = nullptr; double *stat_buf = nullptr;
+    if (inaff) {  // the producer's norm applied to the brick in LDS (INAFF instantiations)
+        std::vector<float> hs((size_t)N * cin), hh((size_t)N * cin);
+        for (auto &v : hs) v = 1.0f + 0.25f * u();
+        for (auto &v : hh) v = 0.1f * u();
+        hipMalloc(&sc, hs.size() * 4); hipMalloc(&sh, hh.size() * 4);
+        hipMemcpy(sc, hs.data(), hs.size() * 4, hipMemcpyHostToDevice); hipMemcpy(sh, hh.data(), hh.size() * 4, hipMemcpyHostToDevice);
+        c.in_scale = sc; c.in_shift = sh; c.in_act = ACT_LRELU;
+    }
+    if (stats) { hipMalloc(&stat_buf, (size_t)N * cout * 16); hipMemset(stat_buf, 0, (size_t)N * cout * 16); c.stats = stat_buf; }
     const char *name = nullptr;
     if (conv3d_mfma_f16(cw, c, 0, &name) != MI355_OK) return 1;
     hipDeviceSynchronize();
@@ -65,6 +75,12 @@ static int run(int N, int D, int cin, int cout, int reps) {
 }
 
 int main() {
+    // the same shape plain, with IN/GN statistics, and with the producer's norm applied in LDS (what INAFF costs, and where)
+    if (run(8, 64, 64, 64, 5)) return 1;
+    if (run(8, 64, 64, 64, 5, false, true)) return 1;
+    if (run(8, 64, 64, 64, 5, true, true)) return 1;
+    if (run(8, 64, 64, 64, 5, true, false)) return 1;
+    return 0;
     // the Cout % 64 == 0 stride-1 launches of bench configs 2 / 3: level 1 64->64, 128->64, level 2 128->128, 256->128
     if (run(8, 64, 64, 64, 5)) return 1;
     if (run(8, 64, 128, 64, 5)) return 1;
