@@ -100,7 +100,8 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
     f32x2 s1[8], s2[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) { s1[r] = f32x2{0.f, 0.f}; s2[r] = f32x2{0.f, 0.f}; }
-    const float slope = p.act == ACT_LRELU ? p.slope : 1.0f;
+    const bool lrelu = p.act == ACT_LRELU;
+    const float slope = lrelu ? p.slope : 1.0f;
     char *img = img_all + wave * E::WAVE_BYTES;
     f32x4 bias[4];
 #pragma unroll
@@ -115,10 +116,10 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
         for (int g = 0; g < 4; ++g) {
             f32x4 val;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float x = acc[mf][4 * g + k] + bias[g][k];
-                x = fmaxf(x, x * slope);
-                val[k] = x;
+            for (int k = 0; k < 4; ++k) val[k] = acc[mf][4 * g + k] + bias[g][k];
+            if (lrelu) {  // (wave-uniform: conv -> norm -> LeakyReLU has no activation here, and this kernel is VALU-bound)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) val[k] = fmaxf(val[k], val[k] * slope);
             }
             if (do_stats) {  // v_pk_add_f32 / v_pk_fma_f32: one instruction per value pair
 #pragma unroll
