@@ -27,6 +27,7 @@ EXPORTS = [
     "mi355_profile_read", "mi355_conv3d_ndhwc_f16", "mi355_tconv3d_ndhwc_f16",
     "mi355_label_remap", "mi355_label_confusion", "mi355_cosine_topk", "mi355_crop_mask", "mi355_label_stats",
     "mi355_last_conv_kernel",
+    "mi355_conv3d_sums_ndhwc",
 ]
 
 
@@ -113,6 +114,8 @@ def load():
     lib.mi355_conv3d_ndhwc_f16.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int,
                                            C.c_int, C.c_int, C.c_float, vp, vp]
     lib.mi355_tconv3d_ndhwc_f16.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, vp, vp]
+    lib.mi355_conv3d_sums_ndhwc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int,
+                                            C.c_int, C.c_int, C.c_float, vp, vp, vp]
     lib.mi355_label_remap.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_uint8), vp]
     lib.mi355_label_confusion.argtypes = [vp, vp, C.c_int64, C.c_int, C.POINTER(C.c_uint64), vp]
     lib.mi355_cosine_topk.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, c_int32_p, c_float_p, vp]

@@ -824,14 +824,17 @@ extern "C" int mi355_sw_predict(const mi355_unet_t *nets, int n_nets, const floa
     return rc;
 }
 
-extern "C" int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
-                                  const float *bias_host, int cout, int stride, int act, float slope, int impl, float *y_dev,
-                                  void *stream) {
+// `sums` (device, [n][cout][2] doubles, zeroed here) != nullptr: the launch also carries the Instance/GroupNorm statistics
+// epilogue (sum x, sum x^2 of its output per sample and channel) exactly as a run-time-norm block of the network does.
+static int conv3d_ndhwc_f32_impl(const float *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
+                                 const float *bias_host, int cout, int stride, int act, float slope, int impl, float *y_dev,
+                                 double *sums, void *stream) {
     MI355_TRY(require_device());
+    if (sums) MI355_HIP(hipMemsetAsync(sums, 0, (size_t)n * cout * 2 * sizeof(double), (hipStream_t)stream));
     if (cin == 4 && stride == 1 && impl == 0 && cout % 32 == 0) {  // the network's first-layer kernel
         StemWeights sw;
         MI355_TRY(stem_weights_upload(weight_host, bias_host, cin, cout, MI355_F32, &sw));
-        int rc = conv3d_stem(sw, x_dev, n, d, h, w, y_dev, nullptr, act, slope, (hipStream_t)stream);
+        int rc = conv3d_stem(sw, x_dev, n, d, h, w, y_dev, sums, act, slope, (hipStream_t)stream);
         g_last_conv_kernel = "conv3_stem_f32_kernel";
         hipError_t e = hipStreamSynchronize((hipStream_t)stream);
         stem_weights_free(&sw);
@@ -842,6 +845,8 @@ extern "C" int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w
     MI355_TRY(conv_weights_upload(weight_host, bias_host, cin, cin, cout, stride, impl == 1, &cw));
     ConvCall c;
     c.in0 = x_dev; c.C0 = cin; c.N = n; c.Di = d; c.Hi = h; c.Wi = w; c.out = y_dev; c.act = act; c.slope = slope;
+    c.stats = sums;
+    MI355_REQUIRE(!sums || impl != 1, "the direct cross-check kernel carries no statistics epilogue");
     const char *kname = "conv3_direct_kernel";
     int rc = (impl == 1) ? conv3d_direct_f32(cw, c, (hipStream_t)stream) : conv3d_mfma_f32(cw, c, (hipStream_t)stream, &kname);
     g_last_conv_kernel = kname ? kname : "";
@@ -849,6 +854,12 @@ extern "C" int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w
     conv_weights_free(&cw);
     if (rc == MI355_OK && e != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
     return rc;
+}
+
+extern "C" int mi355_conv3d_ndhwc(const float *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
+                                  const float *bias_host, int cout, int stride, int act, float slope, int impl, float *y_dev,
+                                  void *stream) {
+    return conv3d_ndhwc_f32_impl(x_dev, n, d, h, w, cin, weight_host, bias_host, cout, stride, act, slope, impl, y_dev, nullptr, stream);
 }
 
 extern "C" int mi355_tconv3d_ndhwc(const float *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
@@ -872,12 +883,13 @@ struct TmpBuf {
 };
 }  // namespace
 
-extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
-                                      const float *bias_host, int cout, int stride, int act, float slope, void *y_dev,
-                                      void *stream) {
+static int conv3d_ndhwc_f16_impl(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
+                                 const float *bias_host, int cout, int stride, int act, float slope, void *y_dev,
+                                 double *sums, void *stream) {
     MI355_TRY(require_device());
     MI355_REQUIRE(stride == 1 || stride == 2, "conv stride %d unsupported", stride);
     hipStream_t s = (hipStream_t)stream;
+    if (sums) MI355_HIP(hipMemsetAsync(sums, 0, (size_t)n * cout * 2 * sizeof(double), s));
     const int64_t Vi = (int64_t)d * h * w;
     const int64_t Vo = (int64_t)((d - 1) / stride + 1) * ((h - 1) / stride + 1) * ((w - 1) / stride + 1);
     MI355_REQUIRE(cout % 8 == 0, "fp16 conv needs cout %% 8 == 0 (got %d)", cout);
@@ -887,7 +899,7 @@ extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, in
     if (cin == 4 && stride == 1 && cout % 32 == 0) {  // the network's first-layer kernel: plain NDHW4 input
         StemWeights sw;
         MI355_TRY(stem_weights_upload(weight_host, bias_host, cin, cout, MI355_F16, &sw));
-        rc = conv3d_stem(sw, x_dev, n, d, h, w, yb.p, nullptr, act, slope, s);
+        rc = conv3d_stem(sw, x_dev, n, d, h, w, yb.p, sums, act, slope, s);
         g_last_conv_kernel = "conv3_stem_f16_kernel";
         if (rc == MI355_OK) rc = b8_to_ndhwc((const _Float16 *)yb.p, n, cout, Vo, (_Float16 *)y_dev, s);
         hipError_t e = hipStreamSynchronize(s);
@@ -903,7 +915,7 @@ extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, in
     MI355_TRY(conv_weights_upload_f16(weight_host, bias_host, cin, cin, cout, stride, &cw));
     ConvCallH c;
     c.in0 = (const _Float16 *)xb.p; c.C0 = cin; c.N = n; c.Di = d; c.Hi = h; c.Wi = w; c.out = (_Float16 *)yb.p;
-    c.act = act; c.slope = slope;
+    c.act = act; c.slope = slope; c.stats = sums;
     const char *kname = nullptr;
     rc = conv3d_mfma_f16(cw, c, s, &kname);
     g_last_conv_kernel = kname ? kname : "";
@@ -912,6 +924,23 @@ extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, in
     conv_weights_free_f16(&cw);
     if (rc == MI355_OK && e != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
     return rc;
+}
+
+extern "C" int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
+                                      const float *bias_host, int cout, int stride, int act, float slope, void *y_dev,
+                                      void *stream) {
+    return conv3d_ndhwc_f16_impl(x_dev, n, d, h, w, cin, weight_host, bias_host, cout, stride, act, slope, y_dev, nullptr, stream);
+}
+
+extern "C" int mi355_conv3d_sums_ndhwc(const void *x_dev, int dtype, int n, int d, int h, int w, int cin, const float *weight_host,
+                                       const float *bias_host, int cout, int stride, int act, float slope, void *y_dev,
+                                       double *sums_dev, void *stream) {
+    MI355_REQUIRE(sums_dev != nullptr, "mi355_conv3d_sums_ndhwc: sums_dev is null");
+    MI355_REQUIRE(dtype == MI355_F32 || dtype == MI355_F16, "unknown dtype %d", dtype);
+    if (dtype == MI355_F16)
+        return conv3d_ndhwc_f16_impl(x_dev, n, d, h, w, cin, weight_host, bias_host, cout, stride, act, slope, y_dev, sums_dev, stream);
+    return conv3d_ndhwc_f32_impl((const float *)x_dev, n, d, h, w, cin, weight_host, bias_host, cout, stride, act, slope, 0, (float *)y_dev,
+                                 sums_dev, stream);
 }
 
 extern "C" int mi355_tconv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,

@@ -123,6 +123,26 @@ def conv3d_ndhwc(x, weight, bias=None, stride=1, act=0, slope=0.01, impl="mfma")
     return y
 
 
+def conv3d_sums_ndhwc(x, weight, bias=None, stride=1, act=0, slope=0.01):
+    """Single conv with the run-time-norm statistics epilogue (test entry point): returns (y, sums) with
+    sums[n, cout] = (sum of y, sum of y^2) over the voxels, fp64 - what InstanceNorm / GroupNorm reduce y to
+    (generic_UNet.py:62-72).  x: CUDA fp32 or fp16 [N,D,H,W,Cin]; weight: numpy [Cout,Cin,3,3,3]."""
+    import torch
+    f16 = x.dtype == torch.float16
+    x = _require_cuda(x, torch.float16 if f16 else torch.float32, "x")
+    n, d, h, w, cin = x.shape
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    cout = weight.shape[0]
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    do, ho, wo = (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1
+    y = torch.empty((n, do, ho, wo, cout), dtype=x.dtype, device=x.device)
+    sums = torch.empty((n, cout, 2), dtype=torch.float64, device=x.device)
+    _lib.check(_lib.load().mi355_conv3d_sums_ndhwc(x.data_ptr(), 1 if f16 else 0, n, d, h, w, cin, _lib.fptr(weight), _lib.fptr(b),
+                                                   cout, stride, act, slope, y.data_ptr(), sums.data_ptr(), _stream(x)),
+               "mi355_conv3d_sums_ndhwc")
+    return y, sums
+
+
 def last_conv_kernel() -> str:
     """Kernel instantiation the last ``conv3d_ndhwc`` call of this thread ran on (test aid)."""
     return (_lib.load().mi355_last_conv_kernel() or b"").decode()

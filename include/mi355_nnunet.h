@@ -199,6 +199,14 @@ int mi355_conv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int ci
                            void *stream);
 int mi355_tconv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, int w, int cin, const float *weight_host,
                             int cout, void *y_dev, void *stream);
+/* One convolution WITH the run-time-norm statistics epilogue: y = act(conv(x) + b) as mi355_conv3d_ndhwc[_f16] (dtype =
+ * MI355_F32 / MI355_F16; plain NDHWC operands of that dtype; the kernel the network would dispatch for this shape), and
+ * sums_dev[n][cout][2] = (sum over voxels of y, sum of y^2) in fp64 - the two numbers nn.InstanceNorm3d / nn.GroupNorm in
+ * ConvDropoutNormNonlin (generic_UNet.py:62-72) reduce their input to, accumulated by the conv kernel's epilogue from the
+ * fp32 values BEFORE any rounding to fp16.  Test aid for the statistics instantiations of every conv kernel. */
+int mi355_conv3d_sums_ndhwc(const void *x_dev, int dtype, int n, int d, int h, int w, int cin, const float *weight_host,
+                            const float *bias_host, int cout, int stride, int act, float slope, void *y_dev,
+                            double *sums_dev, void *stream);
 /* Name of the kernel instantiation the calling thread's last mi355_conv3d_ndhwc / mi355_conv3d_ndhwc_f16 call dispatched
  * (the names rocprofv3 and mi355_profile_read show).  Test aid: a parity case written for one kernel can assert that it
  * ran on that kernel.  No reference counterpart (torch.nn.Conv3d, generic_UNet.py:56, has one implementation). */

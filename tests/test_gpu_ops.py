@@ -210,6 +210,63 @@ def test_conv3d_f16_matches_torch(amd, gpu, case):
         assert ran == F16_EXPECT_KERNEL[case], ran
 
 
+# Norm statistics epilogue (sum y, sum y^2 per sample and channel: what InstanceNorm / GroupNorm reduce the conv output to,
+# generic_UNet.py:62-72), one case per kernel instantiation that carries it.  (n, d, h, w, cin, cout, stride, act, dtype)
+SUMS_CASES = [
+    (8, 32, 32, 32, 64, 64, 1, 0, "f16"),    # LDS-DMA kernel, statistics, no activation (conv -> norm -> LeakyReLU)
+    (4, 24, 40, 72, 16, 64, 1, 1, "f16"),    # the same kernel with an activation in front of the statistics (ConvDropoutNonlinNorm)
+    (2, 64, 64, 64, 32, 128, 2, 0, "f16"),   # stride-2 LDS-DMA kernel
+    (8, 16, 16, 32, 32, 32, 1, 0, "f16"),    # register-staged kernel, 512-voxel tiles, Cout = 32
+    (2, 8, 12, 40, 16, 64, 1, 1, "f16"),     # the same family, ragged tiles: voxels beyond the edge must not count
+    (3, 9, 7, 131, 48, 96, 2, 0, "f16"),     # stride 2, odd dims, ragged
+    (2, 8, 12, 40, 4, 32, 1, 0, "f16"),      # first layer (Cin = 4), ragged in y
+    (1, 16, 16, 32, 4, 64, 1, 1, "f16"),     # first layer, two cout blocks
+    (8, 32, 32, 32, 32, 32, 1, 0, "f32"),    # F(2x2,3x3) Winograd kernel, statistics instantiation
+    (2, 16, 16, 64, 16, 64, 1, 1, "f32"),    # direct f32 kernels
+    (2, 10, 6, 14, 64, 32, 2, 0, "f32"),     # stride 2, ragged
+    (2, 64, 64, 128, 32, 64, 2, 0, "f32"),   # persistent stride-2 kernel
+    (2, 8, 12, 40, 4, 32, 1, 0, "f32"),      # first layer
+]
+SUMS_EXPECT_KERNEL = {
+    (8, 32, 32, 32, 64, 64, 1, 0, "f16"): "conv3_f16_dma_kernel<true, false>",
+    (4, 24, 40, 72, 16, 64, 1, 1, "f16"): "conv3_f16_dma_kernel<true, false>",
+    (2, 64, 64, 64, 32, 128, 2, 0, "f16"): "conv3_f16_s2dma_kernel<true>",
+    (8, 32, 32, 32, 32, 32, 1, 0, "f32"): "conv3_f32_wino2_kernel<2>",
+    (2, 64, 64, 128, 32, 64, 2, 0, "f32"): "conv3_f32_s2dma_kernel<5>",
+}
+
+
+@pytest.mark.parametrize("case", SUMS_CASES)
+def test_conv3d_norm_sums_match_reference(amd, gpu, case):
+    """The statistics the conv kernels accumulate for the run-time norms, against fp64 sums of the reference conv on the
+    same operands.  The kernels sum fp32 values in fp32 partials of 32-512 voxels, quantise each partial (common.h:
+    2^-40 V for sum y, 2^-44 V for sum y^2) and add the partials exactly in fp64: expected agreement is fp32 rounding of a
+    partial, ~1e-6 relative to the channel's rms; the gates below (1e-4 of the rms for the mean, 1e-4 relative for the mean
+    square) leave room for the MFMA's own summation order inside y."""
+    n, d, h, w, cin, cout, stride, act, dt = case
+    rs = np.random.RandomState(23)
+    x = (_rand(rs, n, d, h, w, cin) + 0.25).astype(np.float32)  # (non-zero mean: sum y must not be a sum of cancelling terms only)
+    wt = (_rand(rs, cout, cin, 3, 3, 3) / np.sqrt(cin * 27)).astype(np.float32)
+    b = _rand(rs, cout)
+    if dt == "f16":
+        x = x.astype(np.float16); wt = wt.astype(np.float16).astype(np.float32)
+    ref = _ref_conv(x.astype(np.float32), wt, b, stride, act, 0.01).astype(np.float64)
+    y, sums = amd.ops.conv3d_sums_ndhwc(torch.from_numpy(x).to(gpu), wt, b, stride=stride, act=act, slope=0.01)
+    ran = amd.ops.last_conv_kernel()
+    y = y.float().cpu().numpy(); sums = sums.cpu().numpy()
+    assert np.abs(y - ref).max() <= (2e-3 if dt == "f16" else 2e-5) * max(1.0, np.abs(ref).max()), ran
+    V = ref.shape[1] * ref.shape[2] * ref.shape[3]
+    mean_ref = ref.sum(axis=(1, 2, 3)) / V
+    msq_ref = (ref * ref).sum(axis=(1, 2, 3)) / V
+    rms = np.sqrt(msq_ref)
+    mean_err = np.abs(sums[..., 0] / V - mean_ref) / rms
+    msq_err = np.abs(sums[..., 1] / V - msq_ref) / msq_ref
+    assert mean_err.max() <= 1e-4 and msq_err.max() <= 1e-4, f"mean err {mean_err.max():.2e} rms, mean-square err {msq_err.max():.2e} ({ran})"
+    import os
+    if case in SUMS_EXPECT_KERNEL and not any(k in os.environ for k in ("MI355_CONV_IMPL", "MI355_F16_DMA", "MI355_F16_S2", "MI355_S2_DMA", "MI355_WINOGRAD")):
+        assert ran == SUMS_EXPECT_KERNEL[case], ran
+
+
 def test_conv3d_f16_identity_asymmetric(amd, gpu):
     rs = np.random.RandomState(3)
     x = rs.randint(-8, 9, size=(1, 8, 8, 32, 32)).astype(np.float16)
