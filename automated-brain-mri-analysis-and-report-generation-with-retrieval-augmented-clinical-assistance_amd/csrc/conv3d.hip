@@ -60,7 +60,7 @@ struct ConvArgs {
 // butterfly over the 32 voxel lanes, then LDS across the 4 waves, then one fp64 atomic per cout.
 template <int MF, int NF, int NW = 4>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvArgs &p, int n, int oz0, int oy0,
-                                              int ox0, int co_blk, float *red, bool sync_before_red) {
+                                              int ox0, int co_blk) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
     if (p.head_out) {
@@ -176,7 +176,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MF][NF], const ConvA
     // (round 3) transposing reduction over the 32 voxel lanes (common.h): each lane ends with the total of ONE (cout, statistic)
     // of this wave's MF * 32 voxels and adds it itself - no LDS, no barrier (round 2: 32 NF butterflies, a cross-wave reduction
     // through `red` behind two __syncthreads()).  Quantised partials: exact additions, hence order-independent.
-    (void)red; (void)sync_before_red; (void)tid;
+    (void)tid;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
         const float tot = half32_reduce_scatter(s1[nf], s2[nf], lane);
@@ -385,10 +385,10 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_kernel(ConvArgs p) {
         ConvArgs q = p;
         q.out = p.partial + (size_t)ks * p.out_elems;
         q.bias = p.zero_bias; q.act = ACT_NONE; q.stats = nullptr; q.head_out = nullptr;
-        conv_epilogue<MF, NF>(acc, q, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32, lds, /*sync_before_red=*/false);
+        conv_epilogue<MF, NF>(acc, q, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32);
         return;
     }
-    conv_epilogue<MF, NF>(acc, p, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32, lds, /*sync_before_red=*/false);
+    conv_epilogue<MF, NF>(acc, p, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32);
 }
 
 // out = act(sum_s partial[s] + bias[c]): the slices are added in slice order, so the result does not depend on scheduling
@@ -451,7 +451,6 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_pipe_kernel(PipeArgs pa
     const int IX = p.IX, IY = p.IY;
     const int brickvox = IX * IY * p.IZ;
     const int npieces = 2 * brickvox;
-    float *red = lds + 2 * pa.buf_floats;  // [4 waves][NF*32][2] stats scratch, never aliased with a brick
 
     // this workgroup's tile sequence: XCD group x owns the contiguous range [lo, hi); its workgroups stride through it
     const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
@@ -592,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_mfma_pipe_kernel(PipeArgs pa
         __syncthreads();  // next brick complete and visible; this brick free for the chunk after next
 
         if (ch == p.nchunks - 1) {
-            conv_epilogue<MF, NF>(acc, p, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red, /*sync_before_red=*/false);
+            conv_epilogue<MF, NF>(acc, p, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -793,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_wino_kernel(ConvArgs p) {
             out[2 * pr][0][r] = acc[pr][0][r] + acc[pr][1][r] + acc[pr][2][r];
             out[2 * pr + 1][0][r] = acc[pr][1][r] - acc[pr][2][r] - acc[pr][3][r];
         }
-    conv_epilogue<4, 1>(out, p, n, oz0, oy0, ox0, (int)blockIdx.y * 32, lds, /*sync_before_red=*/false);
+    conv_epilogue<4, 1>(out, p, n, oz0, oy0, ox0, (int)blockIdx.y * 32);
 }
 
 // ------------------------------------------------------------------ host side
@@ -1368,7 +1367,6 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
     const int half = lane >> 5;
     const int l31 = lane & 31;
     float *wring = lds + 2 * S2_BUF_FLOATS;
-    float *red = wring + 2 * S2_WSLOT_FLOATS;
 
     const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
     const int nl = ((int)gridDim.x - xcd + 7) >> 3;
@@ -1500,7 +1498,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
         }
         ConvArgs q = p;
         q.lx = TXL; q.ly = 6 - TXL; q.lz = 1;  // voxel v = wave * 32 + lane: x = v & (TX-1), y = (v >> TXL) & (TY-1), z = v >> 6
-        conv_epilogue<1, 2>(acc, q, cur.n, cur.oz0, cur.oy0, cur.ox0, (int)blockIdx.y * 64, red, /*sync_before_red=*/false);
+        conv_epilogue<1, 2>(acc, q, cur.n, cur.oz0, cur.oy0, cur.ox0, (int)blockIdx.y * 64);
         cur = nxt_tile;
     }
 }
@@ -1807,7 +1805,9 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
             const int gy = w.cout / (32 * w.nf);
             const long units = tiles * gy;
             const size_t brick_bytes = (size_t)b.IX * b.IY * b.IZ * 8 * sizeof(float);
-            int S = (int)((512 + units - 1) / units);
+            // as many slices as still fit the chip in ONE round of workgroups (256 CUs x 2): rounding up (round 2) gave the 8^3 level
+            // 80 x 7 = 560 workgroups - 48 of them ran behind the other 512 and doubled the launch's critical path
+            int S = (int)(512 / units);
             if (S > a.nchunks / 4) S = a.nchunks / 4;
             if (S > 8) S = 8;
             if (units < 256 && S >= 2 && brick_bytes <= 80 * 1024 && w.cout <= 4096) {

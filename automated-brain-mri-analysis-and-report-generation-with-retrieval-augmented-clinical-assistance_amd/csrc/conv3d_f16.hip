@@ -92,7 +92,7 @@ __device__ __forceinline__ void store_f16x4(half_t *ptr, f16x4 v) {
 // its 72-register weight ring the allocator spills)
 template <int MF, int NF, bool HEAD = false, bool SC1 = false, int PATH = -1>
 __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const ConvArgsH &p, int n, int oz0, int oy0,
-                                                  int ox0, int co_blk, float *red) {
+                                                  int ox0, int co_blk) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int TXm = (1 << p.lx) - 1, TYm = (1 << p.ly) - 1;
     const bool lrelu = p.act == ACT_LRELU;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_kernel(ConvArgsH p) {
         }
         return;
     }
-    conv_epilogue_f16<MF, NF>(acc, p, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32, (float *)lds_raw);
+    conv_epilogue_f16<MF, NF>(acc, p, n, oz0, oy0, ox0, (int)blockIdx.y * NF * 32);
 }
 
 // out = fp16(act(sum_s partial[s])), slices added in slice order (slice 0 carries the bias)
@@ -391,7 +391,6 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
     const int brickvox = IX * IY * p.IZ;
     const int npieces = 2 * brickvox;
     const int buf_bytes = 2 * p.plane_bytes;
-    float *red = (float *)(lds_raw + 2 * buf_bytes);
 
     const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
     const int nl = ((int)gridDim.x - xcd + 7) >> 3;
@@ -657,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f16_mfma_pipe_kernel(ConvArgsH p
         __syncthreads();
 
         if (ch == p.nchunks - 1) {
-            conv_epilogue_f16<MF, NF, HEAD>(acc, p, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk, red);
+            conv_epilogue_f16<MF, NF, HEAD>(acc, p, cur.n, cur.oz0, cur.oy0, cur.ox0, co_blk);
             acc_init_bias<MF, NF>(acc, p.bias, co_blk, half);
         }
         if (!have_next) break;
@@ -745,7 +744,6 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     constexpr int IX = G::IX, IY = G::IY;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *red = (float *)(lds_raw + G::RED_OFF);
     float *bias_lds = (float *)(lds_raw + G::BIAS_OFF);
     if (tid < 64) bias_lds[tid] = p.bias[(int)blockIdx.y * NF * 32 + tid];  // (published by the prologue's barrier)
     const int tab_n = p.N * p.C0;  // INAFF: fp16 scale [N][C0], then shift [N][C0]
@@ -1306,7 +1304,9 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
             fill_geometry_h(b, st, 128 * MFs);
             const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
             const long units = tiles * gy;
-            int S = (int)((512 + units - 1) / units);
+            // as many slices as still fit the chip in ONE round of workgroups (256 CUs x 2): rounding up (round 2) gave the 8^3 level
+            // 80 x 7 = 560 workgroups - 48 of them ran behind the other 512 and doubled the launch's critical path
+            int S = (int)(512 / units);
             if (S > a.nchunks / 4) S = a.nchunks / 4;
             if (S > 8) S = 8;
             size_t lds_bytes = (size_t)2 * b.plane_bytes;

@@ -92,7 +92,7 @@ struct StemEpi {
 // form the kernel needs 134 VGPRs and spilled at four workgroups per CU)
 template <typename T, int STATS = -1>
 __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &p, int n, int oz0, int oy0, int ox0,
-                                              int co_blk, float *red, char *img_all) {
+                                              int co_blk, char *img_all) {
     const bool do_stats = STATS < 0 ? p.stats != nullptr : STATS != 0;
     typedef StemEpi<T> E;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 3) void conv3_stem_f32_kernel(StemArgs p) {
                     for (int mf = 0; mf < 4; ++mf)
                         acc[mf] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[(dz * 3 + dy) * 3 + dx][j], a[mf][dx][j], acc[mf], 0, 0, 0);
         }
-    stem_epilogue<float>(acc, p, n, oz0, oy0, ox0, co_blk, (float *)lds, lds + S_BRICK * 16);
+    stem_epilogue<float>(acc, p, n, oz0, oy0, ox0, co_blk, lds + S_BRICK * 16);
 }
 
 // ---------------------------------------------------------------- fp16
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 3) void conv3_stem_f16_kernel(StemArgs p) {
                 acc[mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[dz * 3 + dy], a, acc[mf], 0, 0, 0);
             }
         }
-    stem_epilogue<_Float16, STATS ? 1 : 0>(acc, p, n, oz0, oy0, ox0, co_blk, (float *)lds, lds + S_BRICK * 8);
+    stem_epilogue<_Float16, STATS ? 1 : 0>(acc, p, n, oz0, oy0, ox0, co_blk, lds + S_BRICK * 8);
 }
 
 // ---------------------------------------------------------------- host
