@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, same guide
+NOMINAL_CLOCK_GHZ = 2.4        # the engine clock those peaks are quoted at (same guide)
 PEAK_HBM_GBS = 8000.0
 PATCH = (128, 128, 128)
 DICE_GATE = 0.999  # BASELINE.json north_star: Dice against the reference CPU output >= 0.999
@@ -195,6 +196,17 @@ def roofline_of(prof, dtype, traffic_ok):
                 traffic_source = "profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/collect_profiles.sh)"
         except Exception:
             traffic = None
+    # The clock the chip granted this kernel (DVFS), from the committed GRBM_GUI_ACTIVE passes of the same command: the nominal
+    # peaks are quoted at 2.4 GHz, a power-limited MFMA kernel runs well below it.  Not measured in this run.
+    clock = clock_source = None
+    clk_file = os.path.join(ROOT, "profiles", "kernel_clocks.json")
+    if traffic_ok and os.path.exists(clk_file):
+        try:
+            clock = json.load(open(clk_file)).get(dom_name, {}).get("shader_clock_ghz")
+            if clock is not None:
+                clock_source = "profiles/kernel_clocks.json (committed rocprofv3 --pmc GRBM_GUI_ACTIVE pass of this workload / dispatch durations, tools/kernel_clocks.py)"
+        except Exception:
+            clock = None
     peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_F16_MFMA_TFLOPS
     ratio = EXECUTED_RATIO.get(dom_name, 1.0)
     conv_ms = sum(v["ms"] for k, v in prof.items() if v["flops"] > 0)
@@ -202,6 +214,8 @@ def roofline_of(prof, dtype, traffic_ok):
     return dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                 frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, executed_flop_ratio=round(ratio, 4),
                 frac_executed=round(achieved * ratio / peak, 4), launches=dom["launches"], avg_launch_ms=round(avg_ms, 4),
+                shader_clock_ghz=clock, shader_clock_source=clock_source,
+                frac_executed_at_that_clock=round(achieved * ratio / (peak * clock / NOMINAL_CLOCK_GHZ), 4) if clock else None,
                 algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3),
                 algorithmic_mb_per_launch=round(dom["bytes"] / dom["launches"] / 1e6, 2),
                 time_share=round(dom["ms"] / sum(p["ms"] for p in prof.values()), 4),

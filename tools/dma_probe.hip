@@ -14,6 +14,9 @@
 //   8: rows of 17 voxels, EVEN voxels only (16 B at a 32-B stride: the stride-2 kernel's parity-split planar image)
 //   9: rows of 17 voxels, lanes in the order even voxels then odd voxels (all 272 bytes of a row by one instruction, the lane
 //      order permuted within the row)
+//  10: pattern 7 with the row starting 16 B before a line boundary, as a brick whose origin is one voxel left of a tile does:
+//      16 + 128 + 16 bytes of three lines per row (calibration of FETCH_SIZE for the conv kernels' staging: run under
+//      rocprofv3 --pmc FETCH_SIZE; bytes used per launch = 256 x 4 x 20000 KiB = 20.97 GB)
 // One workgroup of 4 waves per CU, `iters` instructions per wave back to back, vmcnt(8) in flight.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/dma_probe.hip -o tools/dma_probe
 #include <hip/hip_runtime.h>
@@ -32,6 +35,7 @@ __global__ __launch_bounds__(256, 1) void probe(const char *src, unsigned long l
     else if (PATTERN == 3) off = (lane >> 2) * 256 + (lane & 3) * 16;
     else if (PATTERN == 4) off = (lane >> 3) * 256 + (lane & 7) * 16;
     else if (PATTERN == 7) off = (lane / 10) * 2048 + (lane % 10) * 16;
+    else if (PATTERN == 10) off = (lane / 10) * 2048 + 112 + (lane % 10) * 16;
     else if (PATTERN == 8) off = (lane / 9) * 2048 + (lane % 9) * 32;
     else if (PATTERN == 9) { const int r = lane / 17, c = lane % 17; off = r * 2048 + (c < 9 ? 2 * c : 2 * (c - 9) + 1) * 16; }
     else off = lane * 16;
@@ -93,6 +97,7 @@ int main() {
         run<7>("7: blocked layout, rows of 10 voxels x 16 B", window);
         run<8>("8: blocked layout, rows of 17: even voxels only (32-B stride)", window);
         run<9>("9: blocked layout, rows of 17: even then odd voxels (permuted)", window);
+        run<10>("10: blocked layout, rows of 10 voxels starting 16 B before a line", window);
     }
     return 0;
 }

@@ -33,3 +33,5 @@ python3 tools/pmc_aggregate.py --fetch $P/${T}_pmc_fetch_size.csv --write $P/${T
     --note "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of \`python3 bench.py --steps 1 --warmup 0 --no-secondary --no-cpu-baseline\` (round ${T#r}: config 2 f32, 8 tiles per forward; config 3 f16 for the fp16 kernels; tools/collect_profiles.sh); aggregated by tools/pmc_aggregate.py: per-launch means over all launches of the kernel; hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section; it also counts MALL hits, so this is an upper bound on DRAM traffic)"
 python3 tools/sq_summary.py $P/${T}_pmc_sq_f32.csv $P/${T}_pmc_sq_f16.csv > $P/${T}_pmc_sq_summary.txt
 cat $P/${T}_pmc_sq_summary.txt
+python3 tools/kernel_clocks.py $P/${T}_pmc_sq_f16.csv $P/${T}_pmc_sq_f32.csv --json $P/kernel_clocks.json > $P/${T}_kernel_clocks.txt
+cat $P/${T}_kernel_clocks.txt
