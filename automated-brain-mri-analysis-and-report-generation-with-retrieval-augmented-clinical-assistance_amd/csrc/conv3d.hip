@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                     // sc1: the line leaves the XCD's L2 with the store.  Nothing on this XCD reads it again, and kept in L2 the
                     // output (as many bytes as the input at Cin = Cout) evicts brick lines between the two half-line chunks of
                     // a 32-channel voxel: FETCH_SIZE of the 32 -> 32 layer at 128^3 fell by 38 % with this flag alone.
-                    else if (xok[t]) { float *gp = rowp + lane_off + t * t_stride; asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(gp), "v"(val) : "memory"); }
+                    else if (xok[t]) { float *gp = rowp + lane_off + t * t_stride; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(gp), "v"(val) : "memory"); }
                 }
             }
             if constexpr (EPI == 2) {

@@ -1070,6 +1070,22 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
             unsigned img = (unsigned)(size_t)(lds_char *)(lds_raw + G::EPI_OFF) + wave * G::EPI_WAVE_BYTES;
             unsigned wr = img + l31 * G::EPI_PITCH + half * 8;
             asm volatile("" : "+v"(wr));
+#ifndef MI355_H16_SC1
+#define MI355_H16_SC1 1
+#endif
+#ifndef MI355_H16_EPI_SWAP
+#define MI355_H16_EPI_SWAP 1   // 0: round 2's transposition through a wave-private LDS image (A/B builds of tools/h16_probe.hip)
+#endif
+            // swap path: voxel l31 of fragment mf = (z = 2 wave + (mf >> 1), y = 4 (mf & 1) + (l31 >> 3), x = l31 & 7); lanes 32-63 store the
+            // next cout block (one block plane = Vo voxels x 16 B further)
+            const size_t Vo_sw = (size_t)p.Do * p.Ho * p.Wo;
+            // (32-bit, from a laundered lane id, HERE: as a loop invariant of the tile loop the 64-bit form was hoisted to the kernel
+            //  entry and spilled to scratch - and a scratch access is a vector-memory operation the hand-counted vmcnt waits of
+            //  the weight ring do not know of: the statistics instantiations read weights that had not landed)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned lane_off_sw = (unsigned)(ln >> 5) * (unsigned)(Vo_sw * 16) + (unsigned)((((ln & 31) >> 3) * p.Wo + (ln & 7)) * 16);  // (< 2^32: host check)
+            const half_t *obase_sw = p.out + (((size_t)cur.n * (p.Cout >> 3) + (co_blk >> 3)) * Vo_sw + ((size_t)(cur.oz0 + 2 * wave) * p.Ho + cur.oy0) * p.Wo + cur.ox0) * 8;
             // (cout fragment outermost: the statistics of one fragment are 32 live registers, not 64)
             // A statistics epilogue usually follows a convolution WITHOUT activation (conv -> norm -> LeakyReLU): that case
             // skips the 3 VALU instructions per value pair of max(x, slope x) - a wave-uniform choice of two instantiations.
@@ -1086,27 +1102,55 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
 #pragma unroll
                     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
+                        for (int gp = 0; gp < 4; gp += 2) {  // cout blocks g = gp, gp + 1 (8 couts each: 4 in this lane, 4 in lane ^ 32)
                             const f32x2 slope2 = {slope, slope};
-                            f16x4 val;
+                            f16x4 val2[2];
 #pragma unroll
-                            for (int k = 0; k < 4; k += 2) {
-                                const f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
-                                f32x2 m = x;
-                                if constexpr (ACT) {
-                                    f32x2 y;
-                                    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
-                                    asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(x[0]), "v"(y[0]));
-                                    asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(x[1]), "v"(y[1]));
-                                }
-                                val[k] = (half_t)m[0];
-                                val[k + 1] = (half_t)m[1];
-                                if constexpr (STATS) {  // v_pk_add_f32 + v_pk_fma_f32: one instruction each per value PAIR
-                                    s1[2 * g + (k >> 1)] += m;
-                                    s2[2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[2 * g + (k >> 1)]);
+                            for (int gi = 0; gi < 2; ++gi) {
+                                const int g = gp + gi;
+#pragma unroll
+                                for (int k = 0; k < 4; k += 2) {
+                                    const f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
+                                    f32x2 m = x;
+                                    if constexpr (ACT) {
+                                        f32x2 y;
+                                        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
+                                        asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(x[0]), "v"(y[0]));
+                                        asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(x[1]), "v"(y[1]));
+                                    }
+                                    val2[gi][k] = (half_t)m[0];
+                                    val2[gi][k + 1] = (half_t)m[1];
+                                    if constexpr (STATS) {  // v_pk_add_f32 + v_pk_fma_f32: one instruction each per value PAIR
+                                        s1[2 * g + (k >> 1)] += m;
+                                        s2[2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[2 * g + (k >> 1)]);
+                                    }
                                 }
                             }
-                            *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + (nf * 32 + 8 * g) * 2) = val;
+                            if constexpr (MI355_H16_EPI_SWAP != 0) {
+                                // Whole-line stores WITHOUT the trip through LDS (round 3; cdna_hip_programming.md T21).  This lane holds
+                                // couts 0-3 (half 0) or 4-7 (half 1) of blocks gp and gp + 1 for voxel l31; v_permlane32_swap exchanges the
+                                // upper half-wave of its first operand with the lower half-wave of its second, after which lanes 0-31 hold
+                                // all 16 bytes of block gp and lanes 32-63 those of block gp + 1 for voxel l31.  The fragment's 32 voxels
+                                // are four x-rows of 8 (128 B each in a block's plane): one store = 8 whole lines, as before.
+                                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                                u32x2 a = __builtin_bit_cast(u32x2, val2[0]), b = __builtin_bit_cast(u32x2, val2[1]);
+                                // (inline asm: the pair-returning builtin is miscompiled by this hipcc, see common.h; s_nop 1 = the two wait
+                                //  states between a VALU write of an operand and the swap, and again before the store reads the result)
+                                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1"
+                                             : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+                                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                                const u32x4 v = {a[0], a[1], b[0], b[1]};
+                                const char *row = (const char *)(obase_sw + (((size_t)(mf >> 1) * p.Ho + (mf & 1) * 4) * p.Wo + (size_t)(nf * 4 + gp) * Vo_sw) * 8);
+                                const unsigned lo = lane_off_sw;
+                                // (s_nop 1 behind the store: a VALU write of the data registers of a 16-byte store needs a wait state after
+                                //  its issue - hipcc pads its own stores, it does not look into inline asm, and the next pair's v_cvt_pk
+                                //  reuses these four registers at once: without the pad the statistics instantiations stored garbage)
+                                if constexpr (MI355_H16_SC1 != 0) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lo), "v"(v), "s"(row) : "memory");
+                                else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lo), "v"(v), "s"(row) : "memory");
+                            } else {
+                                *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + (nf * 32 + 8 * gp) * 2) = val2[0];
+                                *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + (nf * 32 + 8 * gp + 8) * 2) = val2[1];
+                            }
                         }
                     if constexpr (STATS) {
                         // (round 3) transposing reduction, common.h: every lane ends with ONE total over the 32 voxel lanes of its
@@ -1128,6 +1172,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
             // rows 8 j .. 8 j + 7 of the image are the x-row (z = 2 wave + (j >> 3), y = j & 7) of the tile: 8 voxels x 8 cout blocks.
             // Blocked output: lane -> (block lane >> 3, voxel x = lane & 7): 8 lanes write the 128 contiguous bytes of a block's
             // x-row, a store instruction eight whole lines
+            if constexpr (MI355_H16_EPI_SWAP == 0) {
             unsigned rd = img + (lane & 7) * G::EPI_PITCH + (lane >> 3) * 16;
             asm volatile("" : "+v"(rd));
             const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
@@ -1138,14 +1183,12 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                 const f32x4 v = *(const __attribute__((address_space(3))) f32x4 *)(rd + j * 8 * G::EPI_PITCH);
                 const char *row = (const char *)(obase + ((size_t)(j >> 3) * p.Ho + (j & 7)) * p.Wo * 8);
                 const unsigned lo = lane_off;
-#ifndef MI355_H16_SC1
-#define MI355_H16_SC1 1
-#endif
                 // sc1: the output lines leave the XCD's L2 with the store - nothing on this XCD reads them again, and kept there
                 // they evict the brick lines whose next 32 bytes the next channel chunk is about to fetch
-                if constexpr (MI355_H16_SC1 != 0) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(lo), "v"(v), "s"(row) : "memory");
-                else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(lo), "v"(v), "s"(row) : "memory");
+                if constexpr (MI355_H16_SC1 != 0) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 0" ::"v"(lo), "v"(v), "s"(row) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 0" ::"v"(lo), "v"(v), "s"(row) : "memory");
             });
+            }
         }
         cur = nxt_tile;
         H16_T(t_e1);

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
                 const char *rowp = (const char *)(obase + ((size_t)(j >> 1) * p.Ho + 2 * (j & 1)) * p.Wo * 8);
                 const unsigned lo2 = lane_off;
                 // sc1: nothing on this XCD reads the output again; kept in its L2 the lines would evict brick lines
-                asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(lo2), "v"(v), "s"(rowp) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 0" ::"v"(lo2), "v"(v), "s"(rowp) : "memory");
             });
         }
         cur = nxt_tile;
