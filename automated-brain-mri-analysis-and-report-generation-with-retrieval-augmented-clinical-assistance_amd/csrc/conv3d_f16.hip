@@ -88,6 +88,28 @@ __device__ __forceinline__ void store_f16x4(half_t *ptr, f16x4 v) {
     else *(f16x4 *)ptr = v;
 }
 
+// Two 8-cout blocks of one voxel, 16 bytes per lane (round 3).  In the accumulator layout a lane holds couts 4 half .. + 3 of
+// a block for its voxel l31 and lane ^ 32 the other four.  v_permlane32_swap exchanges the upper half-wave of its first
+// operand with the lower half-wave of its second: afterwards lanes 0-31 hold all 16 bytes of block g (`v0`) and lanes 32-63
+// those of block g + 1 (`v1`), so a wave stores 16 B per lane - half the store instructions of the 8-byte form, and in the
+// channel-blocked layout (common.h) x-consecutive voxels of a block are whole lines.  Must run with every lane active (the
+// caller predicates the STORE, not this).  Inline asm: the pair-returning builtin is miscompiled by this hipcc (common.h);
+// s_nop 1 = the two wait states between a VALU write of an operand and the swap, and before a reader of the result.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t pair_blocks_f16(f16x4 v0, f16x4 v1) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 a = __builtin_bit_cast(u32x2, v0), b = __builtin_bit_cast(u32x2, v1);
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+    return u32x4_t{a[0], a[1], b[0], b[1]};
+}
+template <bool SC1>
+__device__ __forceinline__ void store_16b(half_t *ptr, u32x4_t v) {
+    // (s_nop 1 behind the asm store: a VALU write of a 16-byte store's data registers needs a wait state after its issue)
+    if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+    else *(u32x4_t *)ptr = v;
+}
+
 // PATH: -1 = statistics iff p.stats (runtime), 0 = never, 1 = always (conv3_f16_dma_kernel: with both paths inlined behind
 // its 72-register weight ring the allocator spills)
 template <int MF, int NF, bool HEAD = false, bool SC1 = false, int PATH = -1>
@@ -154,30 +176,35 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
             const int v = (wave * MF + mf) * 32 + l31;
             const int oz = oz0 + (v >> (p.lx + p.ly)), oy = oy0 + ((v >> p.lx) & TYm), ox = ox0 + (v & TXm);
             const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
-            // couts co_blk + 32 nf + 8 g + 4 half .. + 3: block (co_blk >> 3) + 4 nf + g of the blocked output, position 4 half
+            // couts co_blk + 32 nf + 8 g + 4 half .. + 3: block (co_blk >> 3) + 4 nf + g of the blocked output; after pair_blocks_f16
+            // this lane stores block g + half of a block pair (g = 0, 2), all 16 bytes of its voxel
             const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
-            half_t *orow = p.out + (((size_t)n * (p.Cout >> 3) + (co_blk >> 3)) * Vo + ((size_t)oz * p.Ho + oy) * p.Wo + ox) * 8 + 4 * half;
+            half_t *orow = p.out + (((size_t)n * (p.Cout >> 3) + (co_blk >> 3) + half) * Vo + ((size_t)oz * p.Ho + oy) * p.Wo + ox) * 8;
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int gp = 0; gp < 4; gp += 2) {
                     // max(x, slope * x) with packed multiplies and bare v_max_f32 (fmaxf adds a canonicalising max per
                     // value; every VALU instruction of the epilogue is time the matrix pipe stands still)
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
                     const f32x2 slope2 = {slope, slope};
-                    f16x4 val;
+                    f16x4 val2[2];
 #pragma unroll
-                    for (int k = 0; k < 4; k += 2) {
-                        const f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
-                        f32x2 y;
-                        float m0, m1;
-                        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
-                        asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(x[0]), "v"(y[0]));
-                        asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(x[1]), "v"(y[1]));
-                        val[k] = (half_t)m0;
-                        val[k + 1] = (half_t)m1;
-                    }
-                    if (ok) store_f16x4<SC1>(orow + (size_t)(nf * 4 + g) * Vo * 8, val);
+                    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                        for (int k = 0; k < 4; k += 2) {
+                            const int g = gp + gi;
+                            const f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
+                            f32x2 y;
+                            float m0, m1;
+                            asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(slope2));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(x[0]), "v"(y[0]));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(x[1]), "v"(y[1]));
+                            val2[gi][k] = (half_t)m0;
+                            val2[gi][k + 1] = (half_t)m1;
+                        }
+                    const u32x4_t v16 = pair_blocks_f16(val2[0], val2[1]);
+                    if (ok) store_16b<SC1>(orow + (size_t)(nf * 4 + gp) * Vo * 8, v16);
                 }
         }
         return;
@@ -195,23 +222,27 @@ __device__ __forceinline__ void conv_epilogue_f16(f32x16 (&acc)[MF][NF], const C
         const bool ok = (oz < p.Do) && (oy < p.Ho) && (ox < p.Wo);
         const float in = ok ? 1.f : 0.f;  // a voxel beyond a ragged edge adds nothing
         const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
-        half_t *orow = p.out + (((size_t)n * (p.Cout >> 3) + (co_blk >> 3)) * Vo + ((size_t)oz * p.Ho + oy) * p.Wo + ox) * 8 + 4 * half;
+        half_t *orow = p.out + (((size_t)n * (p.Cout >> 3) + (co_blk >> 3) + half) * Vo + ((size_t)oz * p.Ho + oy) * p.Wo + ox) * 8;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f16x4 val;
+            for (int gp = 0; gp < 4; gp += 2) {
+                f16x4 val2[2];
 #pragma unroll
-                for (int k = 0; k < 4; k += 2) {
-                    f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
-                    if (lrelu) x = f32x2{fmaxf(x[0], x[0] * slope), fmaxf(x[1], x[1] * slope)};  // (wave-uniform; conv -> norm -> LeakyReLU has none here)
-                    val[k] = (half_t)x[0];
-                    val[k + 1] = (half_t)x[1];
-                    const f32x2 m = x * f32x2{in, in};
-                    s1[nf][2 * g + (k >> 1)] += m;  // v_pk_add_f32 / v_pk_fma_f32: one instruction per value pair
-                    s2[nf][2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[nf][2 * g + (k >> 1)]);
-                }
-                if (ok) store_f16x4<SC1>(orow + (size_t)(nf * 4 + g) * Vo * 8, val);
+                for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                    for (int k = 0; k < 4; k += 2) {
+                        const int g = gp + gi;
+                        f32x2 x = {acc[mf][nf][4 * g + k], acc[mf][nf][4 * g + k + 1]};
+                        if (lrelu) x = f32x2{fmaxf(x[0], x[0] * slope), fmaxf(x[1], x[1] * slope)};  // (wave-uniform; conv -> norm -> LeakyReLU has none here)
+                        val2[gi][k] = (half_t)x[0];
+                        val2[gi][k + 1] = (half_t)x[1];
+                        const f32x2 m = x * f32x2{in, in};
+                        s1[nf][2 * g + (k >> 1)] += m;  // v_pk_add_f32 / v_pk_fma_f32: one instruction per value pair
+                        s2[nf][2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[nf][2 * g + (k >> 1)]);
+                    }
+                const u32x4_t v16 = pair_blocks_f16(val2[0], val2[1]);  // (every lane active here: only the store is predicated)
+                if (ok) store_16b<SC1>(orow + (size_t)(nf * 4 + gp) * Vo * 8, v16);
             }
         }
     }

@@ -18,9 +18,9 @@
 //     4-way conflicted, and at one weight fragment per 4 MFMAs the LDS delivers half of what the MFMAs consume);
 //   * weights: the (couts 32 w .. 32 w + 31) fragment of the tap in a nine-tap register ring, inline-asm loads with
 //     hand-counted s_waitcnt vmcnt (loads return in order; see conv3_f16_dma_kernel for why the compiler cannot do it);
-//   * epilogue: bias (the accumulators are initialised with it), LeakyReLU, fp16, transposed through a wave-private LDS
-//     image (row = voxel, 80-B pitch: the 8-B writes of 16 consecutive voxels fall on 16 different bank pairs) into stores
-//     of 4 cout blocks x 2 x-rows x 8 voxels: whole 128-B lines of the channel-blocked output (common.h);
+//   * epilogue: bias (the accumulators are initialised with it), LeakyReLU, fp16; a lane holds 4 of a block's 8 couts for its
+//     voxel and lane ^ 32 the other 4: v_permlane32_swap pairs them up and a store instruction writes 2 cout blocks x 4 x-rows
+//     x 8 voxels: whole 128-B lines of the channel-blocked output (common.h) without a transposition through LDS;
 //     sum x and sum x^2 per cout for Instance/GroupNorm as in the other kernels (quantised partials, common.h).
 // The stride-2 convs read one input tensor (no virtual concat) and never carry the fused head.
 #include "kernels.h"
@@ -67,9 +67,8 @@ struct S2GeomH {
     }
     static constexpr int after_last_dma = 27 - EVERY * (KD - 1);        // weight loads issued after the chunk's last piece
     static constexpr int MF_STRIDE = 2 * IY * ROW * 16;                 // fragment mf = output plane z = mf: two input planes further
-    static constexpr int EPI_PITCH = 80, EPI_WAVE_BYTES = 128 * EPI_PITCH;
-    static constexpr int BIAS_OFF = 2 * BUF_BYTES, RED_OFF = BIAS_OFF + 128 * 4, EPI_OFF = RED_OFF + 4 * 64 * 4;
-    static constexpr size_t LDS_BYTES = (size_t)EPI_OFF + 4 * EPI_WAVE_BYTES;
+    static constexpr int BIAS_OFF = 2 * BUF_BYTES;
+    static constexpr size_t LDS_BYTES = (size_t)BIAS_OFF + 128 * 4;     // (the epilogue needs no LDS: stores by v_permlane32_swap)
     static_assert(IZ * IY * ROW <= PLANE_BLOCKS * 64, "plane does not hold the brick");
     static_assert(EVERY * (KD - 1) <= 26 && 4 * KD == 2 * PLANE_BLOCKS, "piece schedule");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -250,11 +249,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
         // before it may move a ring register in the epilogue (see conv3_f16_dma_kernel)
         static_for<0, G::D>([&](auto t_c) { auto &w = wq[decltype(t_c)::value]; S2_WWAIT(w, 0); });
         {
-            typedef __attribute__((address_space(3))) char lds_char;
             const float slope = p.act == ACT_LRELU ? p.slope : 1.0f;  // max(x, 1 x) = x
-            const unsigned img = (unsigned)(size_t)(lds_char *)(lds_raw + G::EPI_OFF) + wave * G::EPI_WAVE_BYTES;
-            unsigned wr = img + l31 * G::EPI_PITCH + half * 8;
-            asm volatile("" : "+v"(wr));
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const bool lrelu = p.act == ACT_LRELU;
             f32x2 s1[8], s2[8];
@@ -262,24 +257,48 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) { s1[r] = f32x2{0.f, 0.f}; s2[r] = f32x2{0.f, 0.f}; }
             }
+            // Whole-line stores without a trip through LDS (as conv3_f16_dma_kernel, round 3): fragment mf is output plane z = mf,
+            // its lane l31 the voxel (y = l31 >> 3, x = l31 & 7); the lane holds couts 4 half .. + 3 of the wave's four 8-cout
+            // blocks.  Per block pair one v_permlane32_swap per dword hands lanes 0-31 the 16 bytes of block gp and lanes 32-63
+            // those of block gp + 1: a store instruction writes 4 x-rows x 128 B in each of two block planes, eight whole lines.
+            // (lane part rebuilt from a laundered lane id here: hoisted out of the tile loop it would be spilled)
+            const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned lane_off = (unsigned)(ln >> 5) * (unsigned)(Vo * 16) + (unsigned)((((ln & 31) >> 3) * p.Wo + (ln & 7)) * 16);  // (< 2^32: host check)
+            const half_t *obase = p.out + (((size_t)cur.n * (p.Cout >> 3) + ((co_blk + wave * 32) >> 3)) * Vo + ((size_t)cur.oz0 * p.Ho + cur.oy0) * p.Wo + cur.ox0) * 8;
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f16x4 val;
+                for (int gp = 0; gp < 4; gp += 2) {
+                    f16x4 val2[2];
 #pragma unroll
-                    for (int k = 0; k < 4; k += 2) {
-                        f32x2 m = {acc[mf][4 * g + k], acc[mf][4 * g + k + 1]};
-                        if (lrelu) m = f32x2{fmaxf(m[0], m[0] * slope), fmaxf(m[1], m[1] * slope)};  // (wave-uniform)
-                        val[k] = (half_t)m[0];
-                        val[k + 1] = (half_t)m[1];
-                        if constexpr (STATS) {  // v_pk_add_f32 / v_pk_fma_f32: one instruction per value pair
-                            s1[2 * g + (k >> 1)] += m;
-                            s2[2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[2 * g + (k >> 1)]);
+                    for (int gi = 0; gi < 2; ++gi) {
+                        const int g = gp + gi;
+#pragma unroll
+                        for (int k = 0; k < 4; k += 2) {
+                            f32x2 m = {acc[mf][4 * g + k], acc[mf][4 * g + k + 1]};
+                            if (lrelu) m = f32x2{fmaxf(m[0], m[0] * slope), fmaxf(m[1], m[1] * slope)};  // (wave-uniform)
+                            val2[gi][k] = (half_t)m[0];
+                            val2[gi][k + 1] = (half_t)m[1];
+                            if constexpr (STATS) {  // v_pk_add_f32 / v_pk_fma_f32: one instruction per value pair
+                                s1[2 * g + (k >> 1)] += m;
+                                s2[2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[2 * g + (k >> 1)]);
+                            }
                         }
                     }
-                    // row = voxel mf * 32 + l31, couts 8 g + 4 half .. + 3 of the wave's 32
-                    *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + g * 16) = val;
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    u32x2 a = __builtin_bit_cast(u32x2, val2[0]), b = __builtin_bit_cast(u32x2, val2[1]);
+                    // (s_nop 1: two wait states between a VALU write of an operand and the swap / before the store reads the result)
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1"
+                                 : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+                    const u32x4 v = {a[0], a[1], b[0], b[1]};
+                    const char *rowp = (const char *)(obase + ((size_t)mf * p.Ho * p.Wo + (size_t)gp * Vo) * 8);
+                    const unsigned lo2 = lane_off;
+                    // sc1: nothing on this XCD reads the output again; kept in its L2 the lines would evict brick lines.  s_nop 1: a
+                    // VALU write of a 16-byte store's data registers needs a wait state after its issue (the next pair reuses them)
+                    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lo2), "v"(v), "s"(rowp) : "memory");
                 }
             if constexpr (STATS) {
                 // transposing reduction over the 32 voxel lanes (common.h): each lane ends with the total of one (cout, statistic)
@@ -289,22 +308,6 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
                 const int c = 8 * (r >> 2) + 4 * half + (r & 3);
                 atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co_blk + wave * 32 + c) * 2 + k, quantise_partial((double)tot, k, (long)p.Do * p.Ho * p.Wo));
             }
-            // image rows 16 j .. 16 j + 15 = output voxels (z = j >> 1, y = 2 (j & 1) + yy, x), yy = 0, 1.  Blocked output (common.h):
-            // lane -> (cout block lane >> 4 of the wave's four, yy = (lane >> 3) & 1, x = lane & 7): eight lanes write the 128
-            // contiguous bytes of a block's x-row
-            unsigned rd = img + (lane & 15) * G::EPI_PITCH + (lane >> 4) * 16;
-            asm volatile("" : "+v"(rd));
-            const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
-            const unsigned lane_off = (unsigned)(((size_t)(lane >> 4) * Vo + ((lane >> 3) & 1) * p.Wo + (lane & 7)) * 16);  // (< 2^32: host check)
-            half_t *obase = p.out + (((size_t)cur.n * (p.Cout >> 3) + ((co_blk + wave * 32) >> 3)) * Vo + ((size_t)cur.oz0 * p.Ho + cur.oy0) * p.Wo + cur.ox0) * 8;
-            static_for<0, 8>([&](auto j_c) {
-                constexpr int j = decltype(j_c)::value;
-                const f32x4 v = *(const __attribute__((address_space(3))) f32x4 *)(rd + j * 16 * G::EPI_PITCH);
-                const char *rowp = (const char *)(obase + ((size_t)(j >> 1) * p.Ho + 2 * (j & 1)) * p.Wo * 8);
-                const unsigned lo2 = lane_off;
-                // sc1: nothing on this XCD reads the output again; kept in its L2 the lines would evict brick lines
-                asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 0" ::"v"(lo2), "v"(v), "s"(rowp) : "memory");
-            });
         }
         cur = nxt_tile;
     }
