@@ -163,6 +163,22 @@ __device__ __forceinline__ float half32_reduce_scatter(const stat_f32x2 (&s1)[8]
     return (b1 ? u[1] : u[0]) + dpp_perm<0x4E>(b1 ? u[0] : u[1]);                                      // lane ^ 2
 }
 
+// Two 8-cout blocks of one voxel, 16 bytes per lane (round 3).  In the accumulator layout a lane holds couts 4 half .. + 3 of
+// a block for its voxel l31 and lane ^ 32 the other four.  v_permlane32_swap exchanges the upper half-wave of its first
+// operand with the lower half-wave of its second: afterwards lanes 0-31 hold all 16 bytes of block g (`v0`) and lanes 32-63
+// those of block g + 1 (`v1`), so a wave stores 16 B per lane - half the store instructions of the 8-byte form, and in the
+// channel-blocked layout (common.h) x-consecutive voxels of a block are whole lines.  Must run with every lane active (the
+// caller predicates the STORE, not this).  Inline asm: the pair-returning builtin is miscompiled by this hipcc (common.h);
+// s_nop 1 = the two wait states between a VALU write of an operand and the swap, and before a reader of the result.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t pair_blocks_f16(f16x4 v0, f16x4 v1) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 a = __builtin_bit_cast(u32x2, v0), b = __builtin_bit_cast(u32x2, v1);
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+    return u32x4_t{a[0], a[1], b[0], b[1]};
+}
+
 // fp16 activation layout (round 3): channel-blocked NDHWC, [N][C / 8][D][H][W][8] ("B8", oneDNN's nCdhw8c).  A voxel's eight
 // channels of one block are the 16 bytes ONE lane feeds the matrix cores (v_mfma_f32_32x32x16_f16 B operand: lane = voxel,
 // channels 8 (lane >> 5) .. + 7), and x-consecutive voxels of a block are contiguous, so

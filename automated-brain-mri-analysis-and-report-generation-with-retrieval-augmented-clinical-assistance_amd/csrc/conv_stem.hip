@@ -112,6 +112,7 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
         const int oy = oy0 + mf;
         const bool ok = (oz < p.D) && (oy < p.H) && (ox0 + l31 < p.W);
         const float in = ok ? 1.f : 0.f;  // a voxel beyond a ragged edge adds nothing to the statistics
+        f16x4 hv[4];  // fp16: the four 8-cout blocks' halves this lane holds
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 val;
@@ -129,28 +130,25 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
                     s2[2 * g + (k >> 1)] = __builtin_elementwise_fma(m, m, s2[2 * g + (k >> 1)]);
                 }
             }
-            char *dst = img + l31 * E::PITCH + (8 * g + 4 * half) * (int)sizeof(T);
-            if (sizeof(T) == 4) *(f32x4 *)dst = val;
-            else {
-                f16x4 hv = {(_Float16)val[0], (_Float16)val[1], (_Float16)val[2], (_Float16)val[3]};
-                *(f16x4 *)dst = hv;
-            }
+            if constexpr (sizeof(T) == 4) *(f32x4 *)(img + l31 * E::PITCH + (8 * g + 4 * half) * 4) = val;
+            else hv[g] = f16x4{(_Float16)val[0], (_Float16)val[1], (_Float16)val[2], (_Float16)val[3]};
         }
-        // (same wave wrote the image: the LDS executes a wave's accesses in order, the compiler inserts the wait)
-        const bool row_ok = (oz < p.D) && (oy < p.H);
         if constexpr (sizeof(T) == 2) {
             // fp16 tensors are channel-blocked ([N][C / 8][V][8], common.h): the fragment's 32 voxels are one x-row, 512 contiguous
-            // bytes in each of the four 8-cout blocks; a store instruction writes two blocks x 32 voxels
+            // bytes in each of the four 8-cout blocks.  Round 3: no transposition through LDS - pair_blocks_f16 (common.h) hands
+            // lanes 0-31 the 16 bytes of block g and lanes 32-63 those of block g + 1 for voxel l31, and a store instruction
+            // writes 32 voxels x two blocks = eight whole lines
             const int64_t V = (int64_t)p.D * p.H * p.W;
             const int64_t vrow = ((int64_t)oz * p.H + oy) * p.W + ox0;
 #pragma unroll
-            for (int j = 0; j < E::STORES; ++j) {
-                const int q = j * 64 + lane, unit = q >> 5, vox = q & 31;
-                const f32x4 v = *(const f32x4 *)(img + vox * E::PITCH + unit * 16);
-                _Float16 *dst = (_Float16 *)p.out + (((int64_t)n * (p.Cout >> 3) + (co_blk >> 3) + unit) * V + vrow + vox) * 8;
-                if (row_ok && ox0 + vox < p.W) *(f32x4 *)dst = v;
+            for (int gp = 0; gp < 4; gp += 2) {
+                const u32x4_t v16 = pair_blocks_f16(hv[gp], hv[gp + 1]);  // (every lane active; only the store is predicated)
+                _Float16 *dst = (_Float16 *)p.out + (((int64_t)n * (p.Cout >> 3) + (co_blk >> 3) + gp + half) * V + vrow + l31) * 8;
+                if (ok) *(u32x4_t *)dst = v16;
             }
         } else {
+            // (same wave wrote the image: the LDS executes a wave's accesses in order, the compiler inserts the wait)
+            const bool row_ok = (oz < p.D) && (oy < p.H);
             char *orow = (char *)p.out + ((((size_t)n * p.D + oz) * p.H + oy) * p.W + ox0) * p.Cout * sizeof(T) + co_blk * sizeof(T);
 #pragma unroll
             for (int j = 0; j < E::STORES; ++j) {
@@ -312,8 +310,8 @@ int conv3d_stem(const StemWeights &w, const void *in, int N, int D, int H, int W
     a.act = act; a.slope = slope;
     dim3 grid((unsigned)tiles, w.cout / 32);
     if (w.dtype == MI355_F16) {
-        if (stats) hipLaunchKernelGGL(conv3_stem_f16_kernel<true>, grid, dim3(256), (size_t)S_BRICK * 8 + 4 * StemEpi<_Float16>::WAVE_BYTES, s, a);
-        else hipLaunchKernelGGL(conv3_stem_f16_kernel<false>, grid, dim3(256), (size_t)S_BRICK * 8 + 4 * StemEpi<_Float16>::WAVE_BYTES, s, a);
+        if (stats) hipLaunchKernelGGL(conv3_stem_f16_kernel<true>, grid, dim3(256), (size_t)S_BRICK * 8, s, a);  // (brick only: the fp16 epilogue stores from registers)
+        else hipLaunchKernelGGL(conv3_stem_f16_kernel<false>, grid, dim3(256), (size_t)S_BRICK * 8, s, a);  // (brick only: the fp16 epilogue stores from registers)
     } else {
         hipLaunchKernelGGL(conv3_stem_f32_kernel, grid, dim3(256), (size_t)S_BRICK * 16 + 4 * StemEpi<float>::WAVE_BYTES, s, a);
     }
