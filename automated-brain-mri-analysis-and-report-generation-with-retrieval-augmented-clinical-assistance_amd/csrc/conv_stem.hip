@@ -42,15 +42,24 @@ __device__ __forceinline__ void stem_stage(const T *in, char *lds, int n, int D,
     typedef typename std::conditional<sizeof(T) == 4, f32x4, f32x2>::type piece_t;
     piece_t v[ITER];
     bool ok[ITER];
+    // Address arithmetic at full rate (round 3): the kernel runs one tile per workgroup, so every thread decodes six brick
+    // positions per tile - with i / 36, r / 6 as v_mul_hi and a 64-bit offset per piece that was 72 v_mul_lo_u32 + 18
+    // v_mad_u64_u32 per wave and tile, quarter-rate instructions worth ~1.7k cycles on a VALU-bound kernel.  Here: exact
+    // reciprocal multiplies in 24 bits (i < 1536, r < 43), the voxel offset relative to the brick origin in 24-bit multiplies
+    // (host check: (S_IZ * H + S_IY) * W < 2^24), and ONE wave-uniform 64-bit base.
+    const long base = (((long)n * D + (oz0 - 1)) * H + (oy0 - 1)) * W + (ox0 - 1);  // voxels; may point one voxel outside (never dereferenced there)
+    const T *inb = in + base * 4;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int i = it * 256 + (int)threadIdx.x;
-        const int r = i / S_IX, bx = i - r * S_IX;
-        const int bz = r / S_IY, by = r - bz * S_IY;
-        const int iz = oz0 - 1 + bz, iy = oy0 - 1 + by, ix = ox0 - 1 + bx;
-        ok[it] = (i < S_BRICK) && ((unsigned)iz < (unsigned)D) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-        const size_t off = ok[it] ? ((((size_t)n * D + iz) * H + iy) * W + ix) * 4 : 0;
-        v[it] = *(const piece_t *)(in + off);
+        const unsigned i = (unsigned)(it * 256) + threadIdx.x;
+        const unsigned r = __umul24(i, 1821u) >> 16, bx = i - __umul24(r, (unsigned)S_IX);  // i / 36 (exact for i < 1536)
+        const unsigned bz = __umul24(r, 43u) >> 8, by = r - bz * 6u;                         // r / 6  (exact for r < 43)
+        const int iz = oz0 - 1 + (int)bz, iy = oy0 - 1 + (int)by, ix = ox0 - 1 + (int)bx;
+        ok[it] = (i < (unsigned)S_BRICK) && ((unsigned)iz < (unsigned)D) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+        const unsigned rel = __umul24(__umul24(bz, (unsigned)H) + by, (unsigned)W) + bx;     // voxels from the brick origin
+        // (an out-of-volume piece reads the sample's first voxel instead: any valid address)
+        const T *src = ok[it] ? inb + (size_t)rel * 4 : in + (size_t)n * D * H * W * 4;
+        v[it] = *(const piece_t *)src;
     }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
@@ -95,7 +104,8 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
                                               int co_blk, char *img_all) {
     const bool do_stats = STATS < 0 ? p.stats != nullptr : STATS != 0;
     typedef StemEpi<T> E;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the row addresses derived from it stay in SGPRs
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 s1[8], s2[8];
 #pragma unroll
@@ -138,13 +148,16 @@ __device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[4], const StemArgs &
             // bytes in each of the four 8-cout blocks.  Round 3: no transposition through LDS - pair_blocks_f16 (common.h) hands
             // lanes 0-31 the 16 bytes of block g and lanes 32-63 those of block g + 1 for voxel l31, and a store instruction
             // writes 32 voxels x two blocks = eight whole lines
+            // (address = wave-uniform 64-bit base + a 32-bit lane part: computed per lane in 64 bits it was nine quarter-rate
+            //  multiplies per store on a VALU-bound kernel; V * 16 < 2^32: host check)
             const int64_t V = (int64_t)p.D * p.H * p.W;
             const int64_t vrow = ((int64_t)oz * p.H + oy) * p.W + ox0;
+            const unsigned lane_off = (unsigned)half * (unsigned)(V * 16) + (unsigned)l31 * 16u;
 #pragma unroll
             for (int gp = 0; gp < 4; gp += 2) {
                 const u32x4_t v16 = pair_blocks_f16(hv[gp], hv[gp + 1]);  // (every lane active; only the store is predicated)
-                _Float16 *dst = (_Float16 *)p.out + (((int64_t)n * (p.Cout >> 3) + (co_blk >> 3) + gp + half) * V + vrow + l31) * 8;
-                if (ok) *(u32x4_t *)dst = v16;
+                char *rowp = (char *)p.out + (((int64_t)n * (p.Cout >> 3) + (co_blk >> 3) + gp) * V + vrow) * 16;
+                if (ok) *(u32x4_t *)(rowp + lane_off) = v16;
             }
         } else {
             // (same wave wrote the image: the LDS executes a wave's accesses in order, the compiler inserts the wait)
@@ -304,6 +317,8 @@ int conv3d_stem(const StemWeights &w, const void *in, int N, int D, int H, int W
     a.tiles_x = ceil_div(W, 32); a.tiles_y = ceil_div(H, 4); a.tiles_z = ceil_div(D, 4);
     const long tiles = (long)a.tiles_x * a.tiles_y * a.tiles_z * N;
     MI355_REQUIRE(tiles < (1l << 30), "stem conv grid too large");
+    MI355_REQUIRE(H < (1 << 20) && W < (1 << 20) && (long)(S_IZ * (long)H + S_IY) * W < (1l << 31) && (long)D * H * W * 16 < (1l << 32),
+                  "stem conv: volume %d x %d x %d too large for the 32-bit staging / store offsets", D, H, W);
     a.div_tiles_per_n = make_fastdiv(a.tiles_x * a.tiles_y * a.tiles_z);
     a.div_tiles_x = make_fastdiv(a.tiles_x);
     a.div_tiles_y = make_fastdiv(a.tiles_y);
