@@ -72,20 +72,32 @@ int norm_finalize(const double *stats, int N, int C, int64_t count, int kind, in
 template <typename T>
 __global__ void norm_apply_kernel(T *x, int64_t total4, int64_t VC4, int C4, const f32x4 *scale, const f32x4 *shift,
                                   int act, float slope) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = i / VC4;
-        const int c4 = (int)(i % C4);
-        const f32x4 sc = scale[n * C4 + c4], sh = shift[n * C4 + c4];
-        f32x4 v = load4<T>(x + i * 4);
+    // four quads per thread and trip, loads first (in place: the compiler cannot hoist a load above the previous store itself)
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total4; i0 += U * stride) {
+        f32x4 v[U];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float y = v[k] * sc[k] + sh[k];
-            if (act == ACT_LRELU)
-                y = y > 0.f ? y : y * slope;
-            v[k] = y;
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < total4) v[u] = load4<T>(x + i * 4);
         }
-        store4<T>(x + i * 4, v);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= total4) continue;
+            const int64_t n = i / VC4;
+            const int c4 = (int)(i % C4);
+            const f32x4 sc = scale[n * C4 + c4], sh = shift[n * C4 + c4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float y = v[u][k] * sc[k] + sh[k];
+                if (act == ACT_LRELU)
+                    y = y > 0.f ? y : y * slope;
+                v[u][k] = y;
+            }
+            store4<T>(x + i * 4, v[u]);
+        }
     }
 }
 
@@ -101,15 +113,30 @@ __global__ void norm_apply_b8_kernel(_Float16 *x, int64_t V, int C, const float 
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s8[k] = sc[k]; h8[k] = sh[k]; }
     _Float16 *base = x + nb * V * 8;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
-        f16x8 h = *(const f16x8 *)(base + v * 8);
+    // Four pieces per thread and trip, all four loads issued before the first store (round 3): the pass works in place, so the
+    // compiler cannot move a load above the previous trip's store by itself, and one 16-B load in flight per thread left the
+    // memory pipe waiting on occupancy alone.
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v0 < V; v0 += U * stride) {
+        f16x8 h[U];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float y = (float)h[k] * s8[k] + h8[k];
-            if (act == ACT_LRELU) y = y > 0.f ? y : y * slope;
-            h[k] = (_Float16)y;
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = v0 + u * stride;
+            if (v < V) h[u] = *(const f16x8 *)(base + v * 8);
         }
-        *(f16x8 *)(base + v * 8) = h;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = v0 + u * stride;
+            if (v >= V) continue;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float y = (float)h[u][k] * s8[k] + h8[k];
+                if (act == ACT_LRELU) y = y > 0.f ? y : y * slope;
+                h[u][k] = (_Float16)y;
+            }
+            *(f16x8 *)(base + v * 8) = h[u];
+        }
     }
 }
 
