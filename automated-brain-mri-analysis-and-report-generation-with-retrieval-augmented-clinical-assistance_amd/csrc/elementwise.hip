@@ -311,24 +311,37 @@ constexpr int HEAD_MAX_CLS = 8;
 // over the widest-resolution tensor of the decoder).
 // `feat` = this sample's feature map, `v` = the voxel, V = voxels per sample.  fp32 tensors are plain NDHWC ([V][C]), fp16
 // tensors channel-blocked ([C / 8][V][8], common.h): either way consecutive lanes (voxels) read consecutive 16-B pieces.
-template <typename T, bool NORM>
-__device__ __forceinline__ void head_dot(const T *feat, int64_t v, int64_t V, const float *__restrict__ w, const float *__restrict__ b,
-                                         int C, int ncls, float *logit, const float *__restrict__ sc = nullptr,
-                                         const float *__restrict__ sh = nullptr, float nslope = 1.0f) {
+// CC > 0: the channel count is a compile-time constant (32: every head of the two BraTS networks) - the piece loop is unrolled and ALL
+// 16-B pieces of the voxel are loaded before the first is used (round 3: as a run-time loop each piece was load -> wait -> use,
+// one load in flight per thread, and head_aggregate ran at 2.0 TB/s with its lanes idle on memory latency).  Same order of
+// additions either way: bit-identical logits.
+template <typename T, bool NORM, int CC>
+__device__ __forceinline__ void head_dot_impl(const T *feat, int64_t v, int64_t V, const float *__restrict__ w, const float *__restrict__ b,
+                                              int Crt, int ncls, float *logit, const float *__restrict__ sc, const float *__restrict__ sh, float nslope) {
+    const int C = CC > 0 ? CC : Crt;
 #pragma unroll
     for (int k = 0; k < HEAD_MAX_CLS; ++k) logit[k] = (k < ncls) ? b[k] : 0.f;
-    constexpr int CW = std::is_same<T, _Float16>::value ? 8 : 4;  // channels per 16-B piece
+    constexpr bool F16 = std::is_same<T, _Float16>::value;
+    constexpr int CW = F16 ? 8 : 4;  // channels per 16-B piece
+    constexpr int NP = CC > 0 ? CC / CW : 1;
+    typedef typename std::conditional<F16, f16x8, f32x4>::type piece_t;
+    piece_t pre[NP];
+    if constexpr (CC > 0) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if constexpr (F16) pre[i] = *(const f16x8 *)(feat + ((int64_t)i * V + v) * 8);
+            else pre[i] = *(const f32x4 *)(feat + v * C + i * 4);
+        }
+    }
+#pragma unroll
     for (int c = 0; c < C; c += CW) {
         float f[CW];
-        if constexpr (std::is_same<T, _Float16>::value) {
-            const f16x8 h = *(const f16x8 *)(feat + ((int64_t)(c >> 3) * V + v) * 8);
+        piece_t h;
+        if constexpr (CC > 0) h = pre[c / CW];
+        else if constexpr (F16) h = *(const f16x8 *)(feat + ((int64_t)(c >> 3) * V + v) * 8);
+        else h = *(const f32x4 *)(feat + v * C + c);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = (float)h[j];
-        } else {
-            const f32x4 q = *(const f32x4 *)(feat + v * C + c);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) f[j] = q[j];
-        }
+        for (int j = 0; j < CW; ++j) f[j] = (float)h[j];
         if constexpr (NORM) {
 #pragma unroll
             for (int j = 0; j < CW; ++j) {
@@ -346,6 +359,13 @@ __device__ __forceinline__ void head_dot(const T *feat, int64_t v, int64_t V, co
                     logit[k] = fmaf(f[q4], wk[q4], fmaf(f[q4 + 1], wk[q4 + 1], fmaf(f[q4 + 2], wk[q4 + 2], fmaf(f[q4 + 3], wk[q4 + 3], logit[k]))));
             }
     }
+}
+template <typename T, bool NORM>
+__device__ __forceinline__ void head_dot(const T *feat, int64_t v, int64_t V, const float *__restrict__ w, const float *__restrict__ b,
+                                         int C, int ncls, float *logit, const float *__restrict__ sc = nullptr,
+                                         const float *__restrict__ sh = nullptr, float nslope = 1.0f) {
+    if (C == 32) head_dot_impl<T, NORM, 32>(feat, v, V, w, b, C, ncls, logit, sc, sh, nslope);  // (wave-uniform)
+    else head_dot_impl<T, NORM, 0>(feat, v, V, w, b, C, ncls, logit, sc, sh, nslope);
 }
 
 template <typename T, bool NORM>
