@@ -28,6 +28,7 @@ EXPORTS = [
     "mi355_label_remap", "mi355_label_confusion", "mi355_cosine_topk", "mi355_crop_mask", "mi355_label_stats",
     "mi355_last_conv_kernel",
     "mi355_conv3d_sums_ndhwc",
+    "mi355_sw_partial_folds", "mi355_sw_finish_folds",
 ]
 
 
@@ -104,6 +105,8 @@ def load():
     lib.mi355_compute_steps.argtypes = [C.c_int, C.c_int, C.c_float, c_int32_p, C.c_int]
     lib.mi355_sw_partial.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(SwOpts), C.c_int, C.c_int, vp, vp, vp]
     lib.mi355_sw_finish.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, c_int32_p, vp, vp]
+    lib.mi355_sw_partial_folds.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(SwOpts), C.c_int, C.c_int, vp, vp, vp]
+    lib.mi355_sw_finish_folds.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, c_int32_p, C.c_int, vp, vp]
     lib.mi355_regions_to_labels.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_int32_p, c_int32_p, c_int32_p, vp, vp]
     lib.mi355_label_ensemble.argtypes = [vp, vp, vp, C.c_int64, vp]
     lib.mi355_prob_mean.argtypes = [vp, vp, vp, C.c_int64, vp]

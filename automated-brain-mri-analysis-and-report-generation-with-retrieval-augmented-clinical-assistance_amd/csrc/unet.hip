@@ -540,13 +540,15 @@ static int make_geom(const mi355_sw_opts &o, int Z, int Y, int X, SwGeom *g) {
 
 // Evaluates the tiles with (index % world) == rank of one net; adds into agg (and cnt if non-null,
 // for ALL tiles so that every rank holds the full normaliser).
+// `first_item`: index of this net's tile 0 in the caller's work list (fold f of a fold list: f * tiles): the work items
+// (fold, tile) are dealt round-robin over the ranks as ONE list, so 5 folds x 8 tiles on 3 ranks still balance.
 static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X, const mi355_sw_opts &o,
-                         const SwGeom &g, int rank, int world, float *agg, float *cnt, hipStream_t s) {
+                         const SwGeom &g, int rank, int world, float *agg, float *cnt, hipStream_t s, long first_item = 0) {
     const int nm = (int)g.mirrors.size();
     const bool use_gauss = o.use_gaussian && g.tiles.size() > 1;
     if (use_gauss) MI355_TRY(ensure_gaussian(net, g.P));
     std::vector<int> mine;
-    for (size_t t = 0; t < g.tiles.size(); ++t) if ((int)(t % world) == rank) mine.push_back((int)t);
+    for (size_t t = 0; t < g.tiles.size(); ++t) if ((int)((first_item + (long)t) % world) == rank) mine.push_back((int)t);
     // samples per forward: 16 (fp32) / 32 (fp16: half the bytes per sample; config 3 fp16 297 -> 293 ms per volume with 32, the
     // deep levels' launches fill the chip better) - the arena is sized for 288 GB of HBM, not for a few GB
     int bt = o.batch_tiles > 0 ? o.batch_tiles : std::max(1, (net->dtype == MI355_F16 ? 32 : 16) / nm);
@@ -555,6 +557,7 @@ static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X,
     Plan pl;
     MI355_TRY(make_plan(*net, bt * nm, g.P[0], g.P[1], g.P[2], &pl));
     MI355_TRY(ensure_arena(net, pl.total));
+    if (mine.empty()) return MI355_OK;
     for (size_t b0 = 0; b0 < mine.size(); b0 += bt) {
         const int nb = (int)std::min<size_t>(bt, mine.size() - b0);
         std::vector<TileDesc> samples;
@@ -765,33 +768,58 @@ extern "C" int mi355_compute_steps(int patch, int image, float step_size, int32_
     return (int)st.size();
 }
 
-extern "C" int mi355_sw_partial(mi355_unet_t net, const float *vol_dev, int Z, int Y, int X, const mi355_sw_opts *opts,
-                                int rank, int world, float *agg_dev, float *cnt_dev, void *stream) {
-    MI355_REQUIRE(net && vol_dev && opts && agg_dev && world >= 1 && rank >= 0 && rank < world, "bad argument");
+// Partitioning B of SURVEY.md 8e with the reference's fold list (run_brats2021_inference_singlethread.py:161 folds=(0..4),
+// :112-128): the work list is (fold, tile), item f * tiles + t, dealt round-robin over the ranks; agg_dev receives
+// sum over this rank's items of the Gaussian-weighted, mirror-averaged probabilities - the fold mean is linear in the
+// per-fold aggregates (mean_f(agg_f / cnt) = (sum_f agg_f) / cnt / n_folds), so ONE exchange per ensemble member suffices.
+extern "C" int mi355_sw_partial_folds(const mi355_unet_t *nets, int n_nets, const float *vol_dev, int Z, int Y, int X,
+                                      const mi355_sw_opts *opts, int rank, int world, float *agg_dev, float *cnt_dev, void *stream) {
+    MI355_REQUIRE(nets && n_nets >= 1 && vol_dev && opts && agg_dev && world >= 1 && rank >= 0 && rank < world, "bad argument");
+    for (int f = 0; f < n_nets; ++f) {
+        MI355_REQUIRE(nets[f] != nullptr, "fold %d: null handle", f);
+        MI355_REQUIRE(nets[f]->num_classes == nets[0]->num_classes, "fold %d has %d classes, fold 0 has %d", f, nets[f]->num_classes, nets[0]->num_classes);
+    }
     MI355_TRY(bind_device());
     hipStream_t s = (hipStream_t)stream;
     SwGeom g;
     MI355_TRY(make_geom(*opts, Z, Y, X, &g));
     const size_t ZYXp = (size_t)g.Zp[0] * g.Zp[1] * g.Zp[2];
-    MI355_HIP(hipMemsetAsync(agg_dev, 0, ZYXp * net->num_classes * sizeof(float), s));
+    MI355_HIP(hipMemsetAsync(agg_dev, 0, ZYXp * nets[0]->num_classes * sizeof(float), s));
     if (cnt_dev) MI355_HIP(hipMemsetAsync(cnt_dev, 0, ZYXp * sizeof(float), s));
     if (cnt_dev && world > 1) {
-        // full normaliser on every rank: cnt[tile] += gaussian for ALL tiles, in tile order
+        // full normaliser of ONE fold on every rank: cnt[tile] += gaussian for ALL tiles, in tile order (no exchange needed)
         const bool use_gauss = opts->use_gaussian && g.tiles.size() > 1;
-        if (use_gauss) MI355_TRY(ensure_gaussian(net, g.P));
+        if (use_gauss) MI355_TRY(ensure_gaussian(nets[0], g.P));
         for (const TileDesc &td : g.tiles)
-            MI355_TRY(cnt_add_tile(use_gauss ? net->gauss_dev : nullptr, g.P[0], g.P[1], g.P[2], cnt_dev, g.Zp[1], g.Zp[2],
+            MI355_TRY(cnt_add_tile(use_gauss ? nets[0]->gauss_dev : nullptr, g.P[0], g.P[1], g.P[2], cnt_dev, g.Zp[1], g.Zp[2],
                                    td.z0, td.y0, td.x0, s));
     }
-    return sw_accumulate(net, vol_dev, Z, Y, X, *opts, g, rank, world, agg_dev, cnt_dev, s);
+    // (world == 1: the first fold's aggregation kernels add the normaliser themselves, exactly as mi355_sw_predict does)
+    for (int f = 0; f < n_nets; ++f)
+        MI355_TRY(sw_accumulate(nets[f], vol_dev, Z, Y, X, *opts, g, rank, world, agg_dev, f == 0 ? cnt_dev : nullptr, s,
+                                (long)f * (long)g.tiles.size()));
+    return MI355_OK;
+}
+
+extern "C" int mi355_sw_partial(mi355_unet_t net, const float *vol_dev, int Z, int Y, int X, const mi355_sw_opts *opts,
+                                int rank, int world, float *agg_dev, float *cnt_dev, void *stream) {
+    return mi355_sw_partial_folds(&net, 1, vol_dev, Z, Y, X, opts, rank, world, agg_dev, cnt_dev, stream);
+}
+
+extern "C" int mi355_sw_finish_folds(const float *agg_dev, const float *cnt_dev, int num_classes, int Z, int Y, int X,
+                                     const int32_t patch[3], int n_folds, float *probs_dev, void *stream) {
+    MI355_REQUIRE(agg_dev && cnt_dev && probs_dev && patch && n_folds >= 1, "bad argument");
+    MI355_TRY(bind_device());
+    const int Zp = std::max(Z, patch[0]), Yp = std::max(Y, patch[1]), Xp = std::max(X, patch[2]);
+    MI355_TRY(finish_probs(agg_dev, cnt_dev, num_classes, Z, Y, X, Zp, Yp, Xp, (Zp - Z) / 2, (Yp - Y) / 2, (Xp - X) / 2,
+                           probs_dev, 0, (hipStream_t)stream));
+    if (n_folds > 1) MI355_TRY(scale_inplace(probs_dev, (int64_t)num_classes * Z * Y * X, (float)n_folds, (hipStream_t)stream));
+    return MI355_OK;
 }
 
 extern "C" int mi355_sw_finish(const float *agg_dev, const float *cnt_dev, int num_classes, int Z, int Y, int X,
                                const int32_t patch[3], float *probs_dev, void *stream) {
-    MI355_TRY(bind_device());
-    const int Zp = std::max(Z, patch[0]), Yp = std::max(Y, patch[1]), Xp = std::max(X, patch[2]);
-    return finish_probs(agg_dev, cnt_dev, num_classes, Z, Y, X, Zp, Yp, Xp, (Zp - Z) / 2, (Yp - Y) / 2, (Xp - X) / 2,
-                        probs_dev, 0, (hipStream_t)stream);
+    return mi355_sw_finish_folds(agg_dev, cnt_dev, num_classes, Z, Y, X, patch, 1, probs_dev, stream);
 }
 
 extern "C" int mi355_sw_predict(const mi355_unet_t *nets, int n_nets, const float *vol_dev, int Z, int Y, int X,
@@ -868,6 +896,7 @@ extern "C" int mi355_tconv3d_ndhwc(const float *x_dev, int n, int d, int h, int 
     TConvWeights tw;
     MI355_TRY(tconv_weights_upload(weight_host, cin, cout, &tw));
     int rc = tconv2_mfma_f32(tw, x_dev, n, d, h, w, y_dev, (hipStream_t)stream);
+    g_last_conv_kernel = "tconv2_f32_mfma_v2_kernel";
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     tconv_weights_free(&tw);
     if (rc == MI355_OK && e != hipSuccess) { set_error("tconv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }
@@ -954,7 +983,9 @@ extern "C" int mi355_tconv3d_ndhwc_f16(const void *x_dev, int n, int d, int h, i
     TConvWeightsH tw;
     MI355_TRY(tconv_weights_upload_f16(weight_host, cin, cout, &tw));
     int rc = ndhwc_to_b8((const _Float16 *)x_dev, n, cin, Vi, (_Float16 *)xb.p, s);
-    if (rc == MI355_OK) rc = tconv2_mfma_f16(tw, (const _Float16 *)xb.p, n, d, h, w, (_Float16 *)yb.p, s);
+    const char *tname = nullptr;
+    if (rc == MI355_OK) rc = tconv2_mfma_f16(tw, (const _Float16 *)xb.p, n, d, h, w, (_Float16 *)yb.p, s, &tname);
+    g_last_conv_kernel = tname ? tname : "";
     if (rc == MI355_OK) rc = b8_to_ndhwc((const _Float16 *)yb.p, n, cout, Vi * 8, (_Float16 *)y_dev, s);
     hipError_t e = hipStreamSynchronize(s);
     tconv_weights_free_f16(&tw);

@@ -80,8 +80,25 @@ class ModelCache:
     def __init__(self):
         self._models = {}
 
+    @staticmethod
+    def _stamp(model_folder, folds):
+        """(mtime_ns, size) of every checkpoint file behind the key: a checkpoint replaced on disk must not be served from
+        stale device weights by a long-lived worker (the per-process path re-reads the files every run)."""
+        out = []
+        for f in folds:
+            for name in ("model_final_checkpoint.model", "model_final_checkpoint.model.pkl"):
+                try:
+                    st = os.stat(os.path.join(str(model_folder), f"fold_{int(f)}", name))
+                    out.append((st.st_mtime_ns, st.st_size))
+                except OSError:
+                    out.append(None)
+        return tuple(out)
+
     def get(self, model_folder, folds, dtype="f32") -> "LoadedModel":
-        key = (str(Path(model_folder).resolve()), tuple(int(f) for f in folds), dtype)
+        base = (str(Path(model_folder).resolve()), tuple(int(f) for f in folds), dtype)
+        key = base + (self._stamp(model_folder, folds),)
+        for old in [k for k in self._models if k[:3] == base and k != key]:
+            self._models.pop(old).close()   # the files changed: drop the stale device copy
         if key not in self._models:
             self._models[key] = LoadedModel(checkpoint.load_model_folder(model_folder, folds, "model_final_checkpoint"), dtype=dtype)
         return self._models[key]

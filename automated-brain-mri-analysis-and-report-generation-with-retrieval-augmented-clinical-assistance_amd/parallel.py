@@ -71,6 +71,12 @@ def shard_tiles(n_tiles: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_tiles, world))
 
 
+def shard_fold_tiles(n_folds: int, n_tiles: int, rank: int, world: int) -> List[tuple]:
+    """The (fold, tile) work items of ``rank`` as ``mi355_sw_partial_folds`` deals them: item ``f * n_tiles + t`` goes to
+    rank ``item % world`` (SURVEY.md 8e partitioning B over the reference's fold list, driver :161)."""
+    return [(i // n_tiles, i % n_tiles) for i in range(rank, n_folds * n_tiles, world)]
+
+
 def sum_partials_in_rank_order(partial, group=None):
     """all_gather the per-rank partial aggregates, then add them 0,1,2,... on every rank."""
     import torch
@@ -78,8 +84,17 @@ def sum_partials_in_rank_order(partial, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return partial
     world = dist.get_world_size(group)
+    if partial.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (ranks sharing one GPU synchronise over gloo, bench.py --backend gloo --share-gpu): stage through the host
+        host = partial.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        total = parts[0].to(partial.device)
+        for r in range(1, world):
+            total += parts[r].to(partial.device)
+        return total
     parts = [torch.empty_like(partial) for _ in range(world)]
-    dist.all_gather(parts, partial.contiguous(), group=group)
+    dist.all_gather(parts, partial.contiguous(), group=group)   # RCCL over xGMI on the "nccl" backend
     total = parts[0].clone()
     for r in range(1, world):
         total += parts[r]
@@ -125,12 +140,16 @@ def predict_cases_sharded(models, cases, rank: int, world: int, patch_size=(128,
 
 def predict_case_tile_sharded(net, data, patch_size=(128, 128, 128), step_size=0.5, do_mirroring=True,
                               mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid", group=None):
-    """Partitioning B end to end on the GPU ranks of ``group``: identical probabilities on every rank."""
+    """Partitioning B end to end on the GPU ranks of ``group``: identical probabilities on every rank.  ``net`` is one
+    network or the fold list of one ensemble member (the reference's five folds, driver :161): the (fold, tile) work list
+    is dealt over the ranks, every rank sums its own items over ALL folds locally, and there is ONE exchange per member
+    (all_gather of the partial aggregates, summed in rank order) - the fold mean is linear in the aggregates."""
     import torch.distributed as dist
     from . import predictor
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_folds = len(net) if isinstance(net, (list, tuple)) else 1
     agg, cnt = predictor.predict_tile_sharded(net, data, rank, world, patch_size, step_size, do_mirroring,
                                               mirror_axes, use_gaussian, nonlin)
     agg = sum_partials_in_rank_order(agg, group)
-    return predictor.finish_sharded(agg, cnt, tuple(data.shape[1:]), patch_size)
+    return predictor.finish_sharded(agg, cnt, tuple(data.shape[1:]), patch_size, n_folds)

@@ -85,32 +85,39 @@ def predict_preprocessed_data_return_seg_and_softmax(net: UNet, data, do_mirrori
     return seg, probs
 
 
-def predict_tile_sharded(net: UNet, data, rank: int, world: int, patch_size=(128, 128, 128), step_size=0.5,
+def predict_tile_sharded(net, data, rank: int, world: int, patch_size=(128, 128, 128), step_size=0.5,
                          do_mirroring=True, mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid",
                          batch_tiles=0, device="cuda"):
-    """This rank's share of one volume (tiles with index % world == rank): returns
-    (agg [K,Zp,Yp,Xp], cnt [Zp,Yp,Xp]); ``finish_sharded`` turns the rank-ordered sum into probabilities."""
+    """This rank's share of one volume: returns (agg [K,Zp,Yp,Xp], cnt [Zp,Yp,Xp]); ``finish_sharded`` turns the
+    rank-ordered sum into probabilities.  ``net`` is one network (tiles with index % world == rank) or the FOLD LIST of
+    one ensemble member (driver :161, :112-128): then the work list is (fold, tile), item ``f * tiles + t`` goes to rank
+    ``item % world``, and ``agg`` is the sum of this rank's items over all folds (``mi355_sw_partial_folds``)."""
     import torch
+    nets = list(net) if isinstance(net, (list, tuple)) else [net]
+    if len(nets) == 0:
+        raise ValueError("no networks given")
     data = _to_device(data, device)
     _, z, y, x = data.shape
     zp, yp, xp = (max(z, patch_size[0]), max(y, patch_size[1]), max(x, patch_size[2]))
-    k = net.topology.num_classes
+    k = nets[0].topology.num_classes
     agg = torch.empty((k, zp, yp, xp), dtype=torch.float32, device=data.device)
     cnt = torch.empty((zp, yp, xp), dtype=torch.float32, device=data.device)
     opts = _opts(patch_size, step_size, use_gaussian, do_mirroring, mirror_axes, nonlin, batch_tiles)
+    handles = (C.c_void_p * len(nets))(*[n.handle for n in nets])
     stream = torch.cuda.current_stream(data.device).cuda_stream
-    _lib.check(_lib.load().mi355_sw_partial(net.handle, data.data_ptr(), z, y, x, C.byref(opts), rank, world,
-                                            agg.data_ptr(), cnt.data_ptr(), stream), "mi355_sw_partial")
+    _lib.check(_lib.load().mi355_sw_partial_folds(handles, len(nets), data.data_ptr(), z, y, x, C.byref(opts), rank, world,
+                                                  agg.data_ptr(), cnt.data_ptr(), stream), "mi355_sw_partial_folds")
     return agg, cnt
 
 
-def finish_sharded(agg, cnt, vol_shape, patch_size):
+def finish_sharded(agg, cnt, vol_shape, patch_size, n_folds=1):
+    """probs = agg / cnt / n_folds, cropped to the unpadded volume (``agg`` = the sum of every rank's partial)."""
     import torch
     k = agg.shape[0]
     z, y, x = vol_shape
     probs = torch.empty((k, z, y, x), dtype=torch.float32, device=agg.device)
     p = (C.c_int32 * 3)(*[int(v) for v in patch_size])
     stream = torch.cuda.current_stream(agg.device).cuda_stream
-    _lib.check(_lib.load().mi355_sw_finish(agg.data_ptr(), cnt.data_ptr(), k, z, y, x, p, probs.data_ptr(), stream),
-               "mi355_sw_finish")
+    _lib.check(_lib.load().mi355_sw_finish_folds(agg.data_ptr(), cnt.data_ptr(), k, z, y, x, p, int(n_folds), probs.data_ptr(),
+                                                 stream), "mi355_sw_finish_folds")
     return probs

@@ -6,8 +6,8 @@ and the checkpoints).  A worker keeps all of it resident:
 
     python -m brats_amd.worker [--results_folder DIR] [--dtype f32|f16] [--folds 0 1 2 3 4] [--socket PATH]
 
-loads both ensemble members once and serves requests on a Unix-domain socket (default
-``/tmp/mi355_nnunet_worker_<uid>.sock``, or ``$MI355_WORKER_SOCKET``).  The drop-in script is then a thin client: it sends
+loads both ensemble members once and serves requests on a Unix-domain socket (``$MI355_WORKER_SOCKET``, else
+``$XDG_RUNTIME_DIR/worker.sock``, else ``/tmp/mi355_nnunet_<uid>/worker.sock`` in a 0700 directory).  The drop-in script is then a thin client: it sends
 its argv, relays the worker's output and exits with its return code; when no worker answers it runs the path in-process as
 before.  One request at a time (one GPU stream, one activation arena - INTEGRATION.md "Stream semantics"); requests from
 concurrent pipelines (``api.py:322-327`` starts one thread per job) queue on the socket, which also serialises the GPU
@@ -29,7 +29,25 @@ import traceback
 
 
 def default_socket_path() -> str:
-    return os.environ.get("MI355_WORKER_SOCKET") or f"/tmp/mi355_nnunet_worker_{os.getuid()}.sock"
+    """$MI355_WORKER_SOCKET, else a socket in a per-user directory nobody else can write: $XDG_RUNTIME_DIR when set (0700 by
+    definition), else /tmp/mi355_nnunet_<uid>/ created 0700 (a predictable name in world-writable /tmp itself could be
+    pre-created by another local user, who would then receive the requests: ADVICE r3)."""
+    if os.environ.get("MI355_WORKER_SOCKET"):
+        return os.environ["MI355_WORKER_SOCKET"]
+    base = os.environ.get("XDG_RUNTIME_DIR")
+    if not (base and os.path.isdir(base) and os.stat(base).st_uid == os.getuid()):
+        base = f"/tmp/mi355_nnunet_{os.getuid()}"
+    return os.path.join(base, "worker.sock")
+
+
+def _owned_by_me(path) -> bool:
+    """The path is a socket owned by this user (lstat: a symlink planted by someone else does not count)."""
+    import stat
+    try:
+        st = os.lstat(path)
+    except OSError:
+        return False
+    return st.st_uid == os.getuid() and stat.S_ISSOCK(st.st_mode)
 
 
 class _SocketWriter(io.TextIOBase):
@@ -73,11 +91,18 @@ def _handle(conn, cache, state):
         with contextlib.redirect_stdout(out):
             try:
                 rc = driver.main(list(req.get("argv", [])), script_dir=req.get("script_dir"), model_cache=cache)
-            except SystemExit as e:  # argparse errors, the reference's sys.exit(1) on a missing model folder
-                rc = e.code if isinstance(e.code, int) else 1
-            except Exception:
+            except SystemExit as e:  # argparse errors, the reference's sys.exit(1) on a missing model folder; sys.exit() = success
+                rc = 0 if e.code is None else (e.code if isinstance(e.code, int) else 1)
+            except Exception as e:
                 print(traceback.format_exc())
                 rc = 1
+                from ._lib import Mi355Error
+                if isinstance(e, Mi355Error) or "HIP" in type(e).__name__ or "hip" in str(e).lower():
+                    # a failed library call or a HIP error may be sticky (a faulted context fails every later launch): answer
+                    # this request, then leave the serve loop so that a supervisor starts a fresh process and later clients
+                    # fall back to in-process runs instead of collecting rc = 1 forever.  Never re-exec a GPU process.
+                    state["run"] = False
+                    state["failed"] = True
     finally:
         try:
             fh.write(json.dumps({"rc": int(rc or 0)}) + "\n")
@@ -90,6 +115,9 @@ def serve(socket_path: str, preload=None, ready_fd=None):
     """Bind, optionally preload (list of (model_dir, folds, dtype)), then serve until a shutdown request."""
     from . import driver
     cache = driver.ModelCache()
+    sock_dir = os.path.dirname(socket_path)
+    if sock_dir and not os.path.isdir(sock_dir):
+        os.makedirs(sock_dir, mode=0o700, exist_ok=True)
     if os.path.exists(socket_path):
         # a stale socket of a dead worker is replaced; a live one answers the ping and we refuse to start a second worker
         with contextlib.suppress(OSError), socket.socket(socket.AF_UNIX, socket.SOCK_STREAM) as probe:
@@ -120,6 +148,8 @@ def serve(socket_path: str, preload=None, ready_fd=None):
         with contextlib.suppress(OSError):
             os.unlink(socket_path)
         cache.close()
+    if state.get("failed"):
+        raise SystemExit(70)  # EX_SOFTWARE: the device path failed; the supervisor restarts the worker
 
 
 def request(argv, script_dir, socket_path=None, out=None, connect_timeout=2.0):
@@ -127,7 +157,7 @@ def request(argv, script_dir, socket_path=None, out=None, connect_timeout=2.0):
     runs the path in-process.  Stdlib only: the drop-in script calls this BEFORE importing torch."""
     path = socket_path or default_socket_path()
     out = out or sys.stdout
-    if os.environ.get("MI355_NO_WORKER") == "1" or not os.path.exists(path):
+    if os.environ.get("MI355_NO_WORKER") == "1" or not os.path.exists(path) or not _owned_by_me(path):
         return None
     try:
         s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)

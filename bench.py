@@ -11,8 +11,13 @@ models A + B, label ensemble) in fp16 and fp32 and an `end_to_end` block (host v
 crop -> z-score -> predict -> labels -> D2H) and a `reference_setting` block: the reference's own per-case setting
 (5 folds x 2 models x 8-way TTA) in fp16 and fp32, one timed step each.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--dtype f32|f16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4] [--dtype f32|f16] [--shard cases|tiles] [--folds F]
                     [--no-cpu-baseline] [--no-secondary] [--no-reference-setting]
+
+--config 3 --shard tiles = SURVEY.md 8e partitioning B (single-case latency): every rank works on the SAME volume, the
+(fold, tile) work list of each ensemble member is dealt round-robin over the ranks (mi355_sw_partial_folds), the partial
+aggregates travel through ONE RCCL all_gather per member and are summed in rank order; a step = that one volume, so this
+mode scales strongly ("scaling": "strong").
 
 --config 4 = BASELINE.json configs[3]: a batch of 32 synthetic volumes (seeds 1000..1031), config-3
 settings, CASES dealt longest-first by tile count over the ranks (SURVEY.md 8e partitioning A, no
@@ -70,6 +75,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-reference-setting", action="store_true", help="skip the 5-fold x 2-model x TTA block of the default run")
     ap.add_argument("--batch-tiles", type=int, default=0)
     ap.add_argument("--cases", type=int, default=0, help="config 4: number of volumes in the batch (default 32)")
+    ap.add_argument("--shard", choices=("cases", "tiles"), default="cases",
+                    help="config 3 with N > 1: 'cases' = one volume per rank per step (weak scaling, no data-path collective); 'tiles' = "
+                         "ONE volume per step for all ranks, its (fold, tile) work list dealt over the ranks and one RCCL all_gather of "
+                         "the partial aggregates per ensemble member (SURVEY.md 8e partitioning B, strong scaling)")
+    ap.add_argument("--folds", type=int, default=1, help="folds per ensemble member (the reference runs 5: driver :161)")
     ap.add_argument("--dtype", choices=("f32", "f16"), default=None, help="default: f32 for config 2, f16 for configs 3 and 4")
     # rehearsal of the N > 1 launch path on a box with fewer GPUs than ranks: ranks share device 0 and synchronise
     # over gloo (RCCL refuses two ranks on one device); never used by the driver
@@ -157,6 +167,34 @@ def build_nets(models, dtype):
     return nets
 
 
+def lib_source_digest():
+    """Digest of csrc/ + headers + flags the in-tree library is built from (the same one lib/libmi355_nnunet.so.digest records)."""
+    try:
+        from brats_amd import _build
+        return _build._library_digest()
+    except Exception:
+        return None
+
+
+def committed_counter(fname, section, kernel, field):
+    """One figure from a committed rocprofv3 --pmc pass (profiles/pmc_traffic.json, profiles/kernel_clocks.json): the value, and
+    whether the pass was taken on a library built from other sources than the one running now (`stale`)."""
+    path = os.path.join(ROOT, "profiles", fname)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        doc = json.load(open(path))
+    except Exception:
+        return None, None
+    entry = (doc.get(section) or {}).get(kernel) if section else None
+    if entry is None:
+        entry = doc.get(kernel) if isinstance(doc.get(kernel), dict) else None
+    if not entry or entry.get(field) is None:
+        return None, None
+    have, now = doc.get("_source_digest"), lib_source_digest()
+    return entry[field], (have is None or now is None or have != now)
+
+
 def timed_region(ctx, step, steps, warmup, nets):
     """W untimed steps, then exactly K steps between two barrier + synchronize brackets; per-kernel HIP-event
     profile of the timed steps (events recorded by the library on the launch stream)."""
@@ -181,40 +219,34 @@ def timed_region(ctx, step, steps, warmup, nets):
     return elapsed, prof, out
 
 
-def roofline_of(prof, dtype, traffic_ok):
-    """Roofline of the kernel with the largest summed HIP-event time over the timed region."""
+def roofline_of(prof, dtype, section):
+    """Roofline of the kernel with the largest summed HIP-event time over the timed region.  `section`: the workload key of
+    the committed counter passes ("config2_f32", "config3_f16", "config3_f32") or None when no pass exists for this workload."""
     dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = dom["ms"] / dom["launches"]
     achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-    traffic = None
-    traffic_source = None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if traffic_ok and os.path.exists(pmc_file):  # the committed PMC passes were taken on these workloads' launch sizes (config 2 f32, config 3 f16)
-        try:
-            traffic = json.load(open(pmc_file)).get(dom_name, {}).get("hbm_bytes_per_launch")
-            if traffic is not None:  # (not measured in this run: the committed rocprofv3 --pmc passes of the same command)
-                traffic_source = "profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/collect_profiles.sh)"
-        except Exception:
-            traffic = None
-    # The clock the chip granted this kernel (DVFS), from the committed GRBM_GUI_ACTIVE passes of the same command: the nominal
-    # peaks are quoted at 2.4 GHz, a power-limited MFMA kernel runs well below it (DESIGN.md section 5).  Not measured in this run.
-    clock = clock_source = None
-    clk_file = os.path.join(ROOT, "profiles", "kernel_clocks.json")
-    if traffic_ok and os.path.exists(clk_file):
-        try:
-            clock = json.load(open(clk_file)).get(dom_name, {}).get("shader_clock_ghz")
-            if clock is not None:
-                clock_source = "profiles/kernel_clocks.json (committed rocprofv3 --pmc GRBM_GUI_ACTIVE pass of this workload / dispatch durations, tools/kernel_clocks.py)"
-        except Exception:
-            clock = None
+    traffic = traffic_source = traffic_stale = None
+    clock = clock_source = clock_stale = None
+    if section:
+        # (not measured in this run: the committed rocprofv3 --pmc passes of the same command on the same launch sizes)
+        traffic, traffic_stale = committed_counter("pmc_traffic.json", section, dom_name, "hbm_bytes_per_launch")
+        if traffic is not None:
+            traffic_source = ("profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                              "tools/collect_profiles.sh; traffic_stale = the pass was taken on a library built from other sources)")
+        # The clock the chip granted this kernel (DVFS), from the committed GRBM_GUI_ACTIVE passes of the same command: the nominal
+        # peaks are quoted at 2.4 GHz, a power-limited MFMA kernel runs well below it (DESIGN.md section 5).
+        clock, clock_stale = committed_counter("kernel_clocks.json", section, dom_name, "shader_clock_ghz")
+        if clock is not None:
+            clock_source = "profiles/kernel_clocks.json (committed rocprofv3 --pmc GRBM_GUI_ACTIVE pass of this workload / dispatch durations, tools/kernel_clocks.py)"
     peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_F16_MFMA_TFLOPS
     ratio = EXECUTED_RATIO.get(dom_name, 1.0)
     conv_ms = sum(v["ms"] for k, v in prof.items() if v["flops"] > 0)
     conv_flops = sum(v["flops"] for v in prof.values())
     return dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, executed_flop_ratio=round(ratio, 4),
+                frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, traffic_stale=traffic_stale,
+                executed_flop_ratio=round(ratio, 4),
                 frac_executed=round(achieved * ratio / peak, 4), launches=dom["launches"], avg_launch_ms=round(avg_ms, 4),
-                shader_clock_ghz=clock, shader_clock_source=clock_source,
+                shader_clock_ghz=clock, shader_clock_source=clock_source, shader_clock_stale=clock_stale,
                 frac_executed_at_that_clock=round(achieved * ratio / (peak * clock / NOMINAL_CLOCK_GHZ), 4) if clock else None,
                 algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3),
                 algorithmic_mb_per_launch=round(dom["bytes"] / dom["launches"] / 1e6, 2),
@@ -245,15 +277,17 @@ class CpuOracle:
 
     def __init__(self, tile):
         self.x = tile.cpu()
-        self.logits = {}
-        self.seconds = {}
+        self.logits = {}     # (name, seed) -> logits of the first tile
+        self.seconds = {}    # name -> (seconds per forward on all cores, forwards timed)
+        self.seconds_8t = None
+        self.cores = None
 
     def forward(self, name, seed, min_forwards=1, budget_s=0.0):
         import torch
         from brats_amd import synthetic
         from oracle import unet_ref
-        if name in self.logits:
-            return self.logits[name]
+        if (name, seed) in self.logits:
+            return self.logits[(name, seed)]
         sd, meta = synthetic.make_model(name, seed=seed)
         cfg = unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])
         if not self.logits:
@@ -262,10 +296,41 @@ class CpuOracle:
         while n < min_forwards or (time.perf_counter() - t0 < budget_s and n < 6):
             out = unet_ref.unet_forward(sd, self.x, cfg)
             n += 1
-        self.seconds[name] = ((time.perf_counter() - t0) / n, n)
-        self.logits[name] = out
+        if name not in self.seconds or n > self.seconds[name][1]:
+            self.seconds[name] = ((time.perf_counter() - t0) / n, n)
+        self.logits[(name, seed)] = out
         self.cores = torch.get_num_threads()
         return out
+
+    def time_8_threads(self, name, seed):
+        """the same forward with torch.set_num_threads(8), to relate the GPU box's host to the survey box
+        (4.72 s per model-A patch at 8 threads)."""
+        import torch
+        from brats_amd import synthetic
+        from oracle import unet_ref
+        sd, meta = synthetic.make_model(name, seed=seed)
+        cfg = unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])
+        before = torch.get_num_threads()
+        torch.set_num_threads(8)
+        try:
+            unet_ref.unet_forward(sd, self.x[:, :, :64, :64, :64], cfg)
+            t0 = time.perf_counter()
+            unet_ref.unet_forward(sd, self.x, cfg)
+            self.seconds_8t = time.perf_counter() - t0
+        finally:
+            torch.set_num_threads(before)
+        return self.seconds_8t
+
+
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def parity_block(got_logits, ref_logits, sample):
@@ -278,11 +343,20 @@ def parity_block(got_logits, ref_logits, sample):
                 dice_wt_tc_et_mean=round(d["mean"], 6))
 
 
-def run_single_volume(ctx, args, config, dtype, steps, warmup, data, props, steps_tbl, oracle=None):
+def parity_probs_block(got, ref, sample):
+    from oracle import tiler_ref
+    lg, lr = tiler_ref.regions_to_labels(got), tiler_ref.regions_to_labels(ref)
+    d = tiler_ref.brats_region_dice(lg, lr)
+    return dict(sample=sample, max_abs_prob_err=float(np.abs(got - ref).max()), labels_differ=int((lg != lr).sum()),
+                voxels=int(lr.size), dice_wt_tc_et_mean=round(d["mean"], 6))
+
+
+def run_single_volume(ctx, args, config, dtype, steps, warmup, data, props, steps_tbl, oracle=None, folds=1, tiles_mode=False):
     """configs 2 / 3: one volume per rank per step.  Returns the result dict (without the top-level contract keys)."""
-    from brats_amd import predictor, ops
+    from brats_amd import predictor, ops, parallel
     wl = WORKLOADS[config]
-    nets = build_nets(wl["models"], dtype)
+    members = [build_nets([(name, seed + k) for k in range(folds)], dtype) for name, seed in wl["models"]]   # [member][fold]
+    nets = [n for m in members for n in m]
     full = props["original_size_of_raw_data"]
     lo = [b[0] for b in props["crop_bbox"]]
     n_tiles = int(np.prod([len(s) for s in steps_tbl]))
@@ -291,20 +365,27 @@ def run_single_volume(ctx, args, config, dtype, steps, warmup, data, props, step
 
     def step():
         segs = []
-        for net in nets:
-            probs = predictor.predict_folds([net], data, PATCH, 0.5, wl["tta"], (0, 1, 2), True, "sigmoid",
-                                            batch_tiles=args.batch_tiles)
+        for fold_nets in members:
+            if tiles_mode:   # partitioning B: this rank's (fold, tile) items, ONE exchange per member, identical result on every rank
+                probs = parallel.predict_case_tile_sharded(fold_nets, data, PATCH, 0.5, wl["tta"], (0, 1, 2), True, "sigmoid")
+            else:
+                probs = predictor.predict_folds(fold_nets, data, PATCH, 0.5, wl["tta"], (0, 1, 2), True, "sigmoid",
+                                                batch_tiles=args.batch_tiles)
             segs.append(ops.regions_to_labels(probs, (1, 2, 3), lo, full))
         return segs[0] if len(segs) == 1 else ops.label_ensemble(segs[0], segs[1])
 
     elapsed, prof, seg = timed_region(ctx, step, steps, warmup, nets)
     res = dict(dtype=dtype, steps=steps, warmup=warmup, ms_per_step=round(elapsed / steps * 1e3, 3),
-               volumes_per_s=round(ctx.world * steps / elapsed, 4),
-               config={"workload": wl["name"], "patch": list(PATCH), "tiles_per_volume": n_tiles, "mirrors": n_mirrors,
+               volumes_per_s=round((1 if tiles_mode else ctx.world) * steps / elapsed, 4),
+               config={"workload": wl["name"] + (f" [{folds} folds per member]" if folds != 1 else ""), "patch": list(PATCH),
+                       "tiles_per_volume": n_tiles, "mirrors": n_mirrors, "folds_per_member": folds,
                        "models": [m[0] for m in wl["models"]], "crop": list(data.shape[1:]),
-                       "sharding": "cases (one volume per rank per step)", "tflop_per_volume": round(flops_per_volume / 1e12, 3)},
-               sustained_tflops_per_gpu=round(flops_per_volume * steps / elapsed / 1e12, 2),
-               roofline=roofline_of(prof, dtype, traffic_ok=((config == 2 and dtype == "f32") or (config == 3 and dtype == "f16")) and not args.batch_tiles),
+                       "sharding": ("tiles: ONE volume per step, the (fold, tile) work list of each ensemble member dealt round-robin over the "
+                                    "ranks, one RCCL all_gather of the partial aggregates per member, rank-ordered sum (SURVEY.md 8e B)")
+                                   if tiles_mode else "cases (one volume per rank per step)",
+                       "tflop_per_volume": round(flops_per_volume / 1e12, 3)},
+               sustained_tflops_per_gpu=round(flops_per_volume * steps / elapsed / 1e12 / (ctx.world if tiles_mode else 1), 2),
+               roofline=roofline_of(prof, dtype, None if (args.batch_tiles or args.folds != 1 or tiles_mode) else f"config{config}_{dtype}"),
                kernels=kernel_table(prof),
                label_histogram=ctx.torch.bincount(seg.flatten().to(ctx.torch.int64), minlength=4).tolist(),
                speedup_vs_nominal_5min=round(300.0 / (elapsed / steps), 1))
@@ -313,9 +394,9 @@ def run_single_volume(ctx, args, config, dtype, steps, warmup, data, props, step
     if oracle is not None and ctx.rank == 0:
         tile = first_tile(data, steps_tbl)
         par = {}
-        for (name, seed), net in zip(wl["models"], nets):
+        for (name, seed), fold_nets in zip(wl["models"], members):
             ref = oracle.forward(name, seed)
-            par[name] = parity_block(net(tile).cpu(), ref, f"first 128^3 tile of the timed volume, model {name} {dtype} GPU forward vs the CPU oracle forward")
+            par[name] = parity_block(fold_nets[0](tile).cpu(), ref, f"first 128^3 tile of the timed volume, model {name} {dtype} GPU forward vs the CPU oracle forward")
         res["parity_vs_cpu_ref"] = par if len(par) > 1 else next(iter(par.values()))
     for n in nets:
         n.close()
@@ -325,11 +406,13 @@ def run_single_volume(ctx, args, config, dtype, steps, warmup, data, props, step
 REFERENCE_FOLDS = 5  # run_brats2021_inference_singlethread.py:161 folds=(0, 1, 2, 3, 4)
 
 
-def run_reference_setting(ctx, dtype, data, props, steps_tbl):
+def run_reference_setting(ctx, dtype, data, props, steps_tbl, oracle=None, steps=3):
     """The reference's own per-case setting as ONE workload (run_brats2021_inference_singlethread.py:161,208-211,263-264):
     two models x five folds x 8-way mirror TTA, fold-mean probabilities per model (:128), region labels, label-round
     ensemble (:305).  Synthetic folds: seeds 7..11 (model A) and 8..12 (model B).  One untimed step (arena growth, first
-    launches), then one timed step."""
+    launches), then `steps` timed steps.  Parity leg (rank 0, when the CPU oracle runs): per ensemble member the FOLD MEAN on
+    the first 128^3 tile of the timed volume (predict_folds on that tile, the five folds, no mirrors) against np.mean of the
+    five CPU-oracle forwards (driver :128), under the same exit-3 gate as every other parity block."""
     from brats_amd import predictor, ops
     torch = ctx.torch
     models = [[("A", 7 + k) for k in range(REFERENCE_FOLDS)], [("B", 8 + k) for k in range(REFERENCE_FOLDS)]]
@@ -349,18 +432,30 @@ def run_reference_setting(ctx, dtype, data, props, steps_tbl):
     step()
     torch.cuda.synchronize(ctx.device)
     t0 = time.perf_counter()
-    seg = step()
+    for _ in range(steps):
+        seg = step()
     torch.cuda.synchronize(ctx.device)
-    dt = time.perf_counter() - t0
+    dt = (time.perf_counter() - t0) / steps
+    res = dict(workload="the reference's per-case setting: models A + B x 5 folds each x 8-way mirror TTA, fold mean, region "
+                        "labels, label-round ensemble (run_brats2021_inference_singlethread.py:161,208-211,263-264)",
+               dtype=dtype, steps=steps, warmup=1, forwards_per_volume=2 * REFERENCE_FOLDS * n_tiles * 8,
+               seconds_per_volume=round(dt, 3), volumes_per_s=round(1.0 / dt, 4), tflop_per_volume=round(flops / 1e12, 1),
+               sustained_tflops_per_gpu=round(flops / dt / 1e12, 1), speedup_vs_nominal_5min=round(300.0 / dt, 1),
+               label_histogram=torch.bincount(seg.flatten().to(torch.int64), minlength=4).tolist())
+    if oracle is not None:
+        tile = first_tile(data, steps_tbl)
+        par = {}
+        for member, folds in zip(models, nets):
+            ref = np.mean([torch.sigmoid(oracle.forward(name, seed))[0].numpy() for name, seed in member], axis=0)   # driver :128
+            got = predictor.predict_folds(folds, tile[0], PATCH, 0.5, False, (0, 1, 2), True, "sigmoid").cpu().numpy()
+            par[member[0][0]] = parity_probs_block(got, ref, f"fold mean of the {REFERENCE_FOLDS} model-{member[0][0]} folds on the first 128^3 tile of the "
+                                                             f"timed volume (no mirrors), {dtype} GPU vs np.mean of {REFERENCE_FOLDS} CPU-oracle forwards")
+        res["parity_vs_cpu_ref"] = par
+    res["_seg"] = seg
     for folds in nets:
         for n in folds:
             n.close()
-    return dict(workload="the reference's per-case setting: models A + B x 5 folds each x 8-way mirror TTA, fold mean, region "
-                         "labels, label-round ensemble (run_brats2021_inference_singlethread.py:161,208-211,263-264)",
-                dtype=dtype, steps=1, warmup=1, forwards_per_volume=2 * REFERENCE_FOLDS * n_tiles * 8,
-                seconds_per_volume=round(dt, 3), volumes_per_s=round(1.0 / dt, 4), tflop_per_volume=round(flops / 1e12, 1),
-                sustained_tflops_per_gpu=round(flops / dt / 1e12, 1), speedup_vs_nominal_5min=round(300.0 / dt, 1),
-                label_histogram=torch.bincount(seg.flatten().to(torch.int64), minlength=4).tolist())
+    return res
 
 
 def run_end_to_end(ctx, raw, steps=3):
@@ -446,7 +541,7 @@ def run_config4(ctx, args, dtype):
                         "sharding": "cases longest-first (tile count) onto the least loaded rank, no data-path collective",
                         "tflop_per_batch": round(flops_batch / 1e12, 2)},
                 sustained=flops_batch * args.steps / elapsed / 1e12 / ctx.world,
-                roofline=roofline_of(prof, dtype, traffic_ok=False), kernels=kernel_table(prof), label_histogram=hist)
+                roofline=roofline_of(prof, dtype, None), kernels=kernel_table(prof), label_histogram=hist)
 
 
 def main(argv=None):
@@ -473,7 +568,10 @@ def main(argv=None):
         ctx.close()
         return
 
-    raw = synthetic.make_volume(seed=1000 + ctx.rank)
+    tiles_mode = args.shard == "tiles"
+    if tiles_mode and args.config != 3:
+        raise SystemExit("--shard tiles is the single-case latency mode of config 3 (SURVEY.md 8e partitioning B)")
+    raw = synthetic.make_volume(seed=1000 + (0 if tiles_mode else ctx.rank))   # tiles mode: every rank works on the SAME case
     data, props = preprocessing.preprocess_case(raw, ctx.device)
     steps_tbl = [ops.compute_steps(PATCH[a], max(PATCH[a], data.shape[1 + a]), 0.5) for a in range(3)]
     want_cpu = not args.no_cpu_baseline and ctx.world == 1
@@ -483,11 +581,12 @@ def main(argv=None):
         name, seed = WORKLOADS[args.config]["models"][0]
         oracle.forward(name, seed, min_forwards=2, budget_s=10.0)  # >= 2 timed forwards, about 10 s of CPU work
 
-    main_res = run_single_volume(ctx, args, args.config, dtype, args.steps, args.warmup, data, props, steps_tbl, oracle)
+    main_res = run_single_volume(ctx, args, args.config, dtype, args.steps, args.warmup, data, props, steps_tbl, oracle,
+                                 folds=args.folds, tiles_mode=tiles_mode)
     flops_per_volume, elapsed = main_res.pop("_flops_per_volume"), main_res.pop("_elapsed")
 
     secondary = None
-    if args.config == 2 and dtype == "f32" and ctx.world == 1 and not args.no_secondary and not args.batch_tiles:
+    if args.config == 2 and dtype == "f32" and ctx.world == 1 and not args.no_secondary and not args.batch_tiles and args.folds == 1:
         # BASELINE.json configs[2] under the same clock and the same oracle tile (3 steps each), and the PCIe-inclusive leg
         secondary = {}
         for dt in ("f16", "f32"):
@@ -496,7 +595,16 @@ def main(argv=None):
             secondary[f"config3_{dt}"] = r
         secondary["end_to_end"] = run_end_to_end(ctx, raw)
         if not args.no_reference_setting:
-            secondary["reference_setting"] = {dt: run_reference_setting(ctx, dt, data, props, steps_tbl) for dt in ("f16", "f32")}
+            ref = {dt: run_reference_setting(ctx, dt, data, props, steps_tbl, oracle) for dt in ("f16", "f32")}
+            # the fp16 label volume against the fp32 label volume of the same run, all 155 x 240 x 240 voxels (a consistency check of
+            # the two paths of this library; the oracle's verdict on each is the fold-mean parity block above)
+            from oracle import tiler_ref
+            seg16, seg32 = ref["f16"].pop("_seg").cpu().numpy(), ref["f32"].pop("_seg").cpu().numpy()
+            d = tiler_ref.brats_region_dice(seg16, seg32)
+            ref["f16"]["consistency_vs_f32_labels"] = dict(sample="ensembled label volume of the timed case, fp16 path vs fp32 path of this run, all voxels",
+                                                            labels_differ=int((seg16 != seg32).sum()), voxels=int(seg16.size),
+                                                            dice_wt_tc_et_mean=round(d["mean"], 6))
+            secondary["reference_setting"] = ref
 
     if ctx.rank != 0:
         ctx.close()
@@ -510,7 +618,11 @@ def main(argv=None):
         flops_model0 = _net.topology_from_state_dict(sd).conv_flops(PATCH)
         est_volume_s = per_fw * flops_per_volume / flops_model0
         cfgd = main_res["config"]
-        cpu = dict(value=round(1.0 / est_volume_s, 6), unit="volumes/s", cores=oracle.cores, kind="port",
+        t8 = oracle.time_8_threads(name, seed)
+        cpu = dict(value=round(1.0 / est_volume_s, 6), unit="volumes/s", cores=oracle.cores, kind="port", cpu_model=cpu_model_string(),
+                   host_logical_cpus=os.cpu_count(),
+                   eight_threads=dict(forward_s=round(t8, 2), value=round(1.0 / (t8 * flops_per_volume / flops_model0), 6), unit="volumes/s",
+                                      note="the same forward with torch.set_num_threads(8) (SURVEY.md 8d: the survey box ran 4.72 s per model-A patch at 8 threads)"),
                    sample=f"{n_fw} forwards of model {name} on the first 1x4x128^3 tile of the timed volume with the torch-CPU fp32 "
                           f"oracle ({per_fw:.2f} s each), scaled by flops to the "
                           f"{cfgd['tiles_per_volume'] * cfgd['mirrors'] * len(cfgd['models'])} forwards of one volume",
@@ -521,7 +633,7 @@ def main(argv=None):
     out = {
         "metric": "BraTS volumes/sec (4-modality 240x240x155)", "value": main_res["volumes_per_s"], "unit": "volumes/s",
         "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if tiles_mode else "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": main_res["config"], "sustained_tflops_per_gpu": main_res["sustained_tflops_per_gpu"],
         "roofline": main_res["roofline"], "cpu_baseline": cpu, "parity_vs_cpu_ref": main_res.get("parity_vs_cpu_ref"),
         "kernels": main_res["kernels"], "label_histogram": main_res["label_histogram"],
@@ -534,13 +646,28 @@ def main(argv=None):
     # north_star gate: Dice of the GPU label map against the CPU oracle's on the same tile >= 0.999, for every parity block of
     # this run; the line above is printed either way, a miss makes the run fail (the bench asserted nothing)
     misses = []
-    blocks = [("main", out.get("parity_vs_cpu_ref"))] + [(k, v.get("parity_vs_cpu_ref")) for k, v in (secondary or {}).items() if isinstance(v, dict)]
-    for where, par in blocks:
-        if not par:
-            continue
-        for name, blk in (par.items() if "dice_wt_tc_et_mean" not in par else [("", par)]):
-            if blk["dice_wt_tc_et_mean"] < DICE_GATE:
-                misses.append(f"{where}{'/' + name if name else ''}: Dice {blk['dice_wt_tc_et_mean']} < {DICE_GATE}")
+
+    def gate(where, node):
+        """Every dict that carries `dice_wt_tc_et_mean` anywhere below a parity / consistency key is gated."""
+        if not isinstance(node, dict):
+            return
+        if "dice_wt_tc_et_mean" in node:
+            if node["dice_wt_tc_et_mean"] < DICE_GATE:
+                misses.append(f"{where}: Dice {node['dice_wt_tc_et_mean']} < {DICE_GATE}")
+            return
+        for k, v in node.items():
+            gate(f"{where}/{k}", v)
+
+    def walk(where, node):
+        if not isinstance(node, dict):
+            return
+        for k, v in node.items():
+            if k in ("parity_vs_cpu_ref", "consistency_vs_f32_labels"):
+                gate(f"{where}/{k}", v)
+            elif isinstance(v, dict) and k in ("secondary", "reference_setting", "config3_f16", "config3_f32", "f16", "f32"):
+                walk(f"{where}/{k}", v)
+
+    walk("", out)
     if misses:
         print("PARITY GATE MISSED: " + "; ".join(misses), file=sys.stderr)
         sys.exit(3)

@@ -134,6 +134,18 @@ int mi355_sw_partial(mi355_unet_t net, const float *vol_dev, int Z, int Y, int X
                      void *stream);
 int mi355_sw_finish(const float *agg_dev, const float *cnt_dev, int num_classes, int Z, int Y, int X,
                     const int32_t patch[3], float *probs_dev, void *stream);
+/* The same with the reference's FOLD LIST (run_brats2021_inference_singlethread.py:161 folds=(0,1,2,3,4); :112-128 one
+ * prediction per fold, np.mean over them): the work list is (fold, tile), item f * tiles + t, and item i belongs to rank
+ * i % world.  agg_dev = sum over this rank's items of the Gaussian-weighted, mirror-averaged probabilities; the fold mean is
+ * linear in the per-fold aggregates - mean_f(agg_f / cnt) = (sum_f agg_f) / cnt / n_folds - so ONE exchange of agg_dev per
+ * ensemble member serves all folds (SURVEY.md 8e partitioning B: "(tile x mirror [x fold x model]) work list").
+ * mi355_sw_finish_folds: probs = agg / cnt / n_folds on the rank-ordered sum of the partial aggregates (equals the per-fold
+ * normalise-then-average of mi355_sw_predict up to fp32 rounding of the division order). */
+int mi355_sw_partial_folds(const mi355_unet_t *nets, int n_nets, const float *vol_dev, int Z, int Y, int X,
+                           const mi355_sw_opts *opts, int rank, int world, float *agg_dev, float *cnt_dev,
+                           void *stream);
+int mi355_sw_finish_folds(const float *agg_dev, const float *cnt_dev, int num_classes, int Z, int Y, int X,
+                          const int32_t patch[3], int n_folds, float *probs_dev, void *stream);
 
 /* seg = 0; for i in 0..C-1: seg[probs[i] > 0.5] = order[i]; pasted at bbox_lo into a zeroed
  * [full_z][full_y][full_x] uint8 volume.  order == NULL: seg = argmax over the C channels (first maximum wins), what

@@ -91,6 +91,57 @@ def test_checkpoint_folder_round_trip_and_safe_unpickle(amd, tmp_path):
         assert list(p["plans_per_stage"][0]["patch_size"]) == [128, 128, 128] and p["base_num_features"] == 32
 
 
+def test_default_plans_equal_the_references_plans_field_by_field(amd):
+    """pin what the reference DOES hold.  data/temp_inference_output1 is the Task500_BraTS2021 plans file
+    the reference ships; every field of checkpoint.default_brats_plans() (what synthetic model folders, the smoke run and the
+    bench are built from) must equal it, and preprocessing.check_plans / check_spacing must accept it as it is - i.e. the
+    path's assumptions (identity transpose, nonCT + use_mask_for_norm on four modalities, 1 mm target spacing, 128^3 patch,
+    five 2x2x2 poolings, 3x3x3 convs) are the reference's own, not ours.  Build container only (the file is not on the GPU box)."""
+    ref_plans = "/root/reference/data/temp_inference_output1"
+    if not os.path.exists(ref_plans):
+        pytest.skip("reference tree absent (GPU box)")
+    ck, pre = amd.checkpoint, amd.preprocessing
+    ref = ck.safe_pickle_load(ref_plans)
+    ours = ck.default_brats_plans()
+
+    def norm(v):
+        if isinstance(v, dict):
+            return {int(k) if not isinstance(k, str) else k: norm(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple, np.ndarray)):
+            return [norm(x) for x in (v.tolist() if isinstance(v, np.ndarray) else v)]
+        if isinstance(v, (np.integer, np.bool_)):
+            return int(v)
+        if isinstance(v, np.floating):
+            return float(v)
+        return v
+
+    for key, val in ours.items():
+        if key == "plans_per_stage":
+            continue
+        assert key in ref, key
+        assert norm(ref[key]) == norm(val), (key, ref[key], val)
+    assert sorted(ref["plans_per_stage"]) == sorted(ours["plans_per_stage"]) == [0]
+    for key, val in ours["plans_per_stage"][0].items():
+        assert norm(ref["plans_per_stage"][0][key]) == norm(val), (key, ref["plans_per_stage"][0][key], val)
+    # fields the path relies on without carrying them in its default plans
+    st = ref["plans_per_stage"][0]
+    assert norm(st["original_spacing"]) == [1.0, 1.0, 1.0] and norm(st["num_pool_per_axis"]) == [5, 5, 5]
+    assert ref["preprocessor_name"] == "GenericPreprocessor" and ref["conv_per_stage"] == 2
+    assert ref["keep_only_largest_region"] is None and ref["min_region_size_per_class"] is None   # no plans-driven post-processing
+    # the product's own gatekeepers accept the reference's plans unchanged ...
+    assert list(pre.check_plans(ref, 4)) == [True, True, True, True]
+    pre.check_spacing(ref, (1.0, 1.0, 1.0), (155, 240, 240))
+    assert norm(pre._stage_plans(ref)["patch_size"]) == [128, 128, 128]
+    # ... and refuse what they do not implement, on the reference's plans with one field changed
+    bad = dict(ref, transpose_forward=[1, 0, 2])
+    with pytest.raises(pre.UnsupportedPlansError):
+        pre.check_plans(bad, 4)
+    with pytest.raises(pre.UnsupportedPlansError):
+        pre.check_plans(dict(ref, normalization_schemes={0: "CT", 1: "nonCT", 2: "nonCT", 3: "nonCT"}), 4)
+    # the tile counts the plans' size statistics imply (SURVEY.md appendix A) through the product's step table
+    assert amd.parallel.tiles_of_shape(norm(st["median_patient_size_in_voxels"])) == 8
+
+
 def test_calculate_volumes_uses_label_4(amd, tmp_path):
     seg = np.zeros((4, 4, 4), np.uint8)
     seg[0, 0, :3] = 1

@@ -46,6 +46,63 @@ def _partial_oracle(sd, vol, patch, rank, world):
     return agg, cnt, idx
 
 
+def _partial_oracle_folds(sds, vol, patch, rank, world, par):
+    """This rank's share of the (fold, tile) work list exactly as mi355_sw_partial_folds deals it (parallel.shard_fold_tiles):
+    agg = sum over the rank's items of gaussian x sigmoid(net_fold(tile)), cnt = the one-fold normaliser."""
+    from oracle import tiler_ref, unet_ref
+    padded, lo = tiler_ref.pad_to_patch(vol, patch)
+    steps = tiler_ref.compute_steps_for_sliding_window(patch, padded.shape[1:], 0.5)
+    g = tiler_ref.get_gaussian(patch)
+    tiles = [(z, y, x) for z in steps[0] for y in steps[1] for x in steps[2]]
+    agg = np.zeros((3,) + padded.shape[1:], np.float32)
+    cnt = np.zeros(padded.shape[1:], np.float32)
+    for z, y, x in tiles:
+        cnt[z:z + patch[0], y:y + patch[1], x:x + patch[2]] += g
+    fns = [tiler_ref.make_net_fn(sd, unet_ref.default_cfg("batch")) for sd in sds]
+    for f, t in par.shard_fold_tiles(len(sds), len(tiles), rank, world):
+        z, y, x = tiles[t]
+        sl = (slice(z, z + patch[0]), slice(y, y + patch[1]), slice(x, x + patch[2]))
+        tin = torch.from_numpy(np.ascontiguousarray(padded[(slice(None),) + sl][None]))
+        agg[(slice(None),) + sl] += tiler_ref.mirror_and_predict(fns[f], tin, (0, 1, 2), False, "sigmoid", torch.from_numpy(g))[0].numpy()
+    return agg, cnt, lo
+
+
+def _worker_folds(rank, world, port, tmp):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import brats_amd
+    from oracle import tiler_ref, unet_ref
+    brats_amd.parallel.init_distributed("gloo")
+    sds = [brats_amd.synthetic.make_model("A", seed=21 + k, num_pool=2, max_feat=64)[0] for k in range(3)]
+    vol = np.random.RandomState(8).standard_normal((4, 24, 40, 20)).astype(np.float32)   # 2 x 4 x 2 = 16 tiles x 3 folds over 2 ranks
+    patch = (16, 16, 16)
+    agg, cnt, lo = _partial_oracle_folds(sds, vol, patch, rank, world, brats_amd.parallel)
+    total = brats_amd.parallel.sum_partials_in_rank_order(torch.from_numpy(agg))          # ONE exchange for all folds
+    probs = (total.numpy() / cnt[None] / np.float32(len(sds)))[:, lo[0]:lo[0] + 24, lo[1]:lo[1] + 40, lo[2]:lo[2] + 20]
+    want = np.mean([tiler_ref.predict_3d_tiled(tiler_ref.make_net_fn(sd, unet_ref.default_cfg("batch")), vol, patch, 3, 0.5,
+                                               False, (0, 1, 2), True, "sigmoid") for sd in sds], axis=0)   # driver :128
+    assert np.abs(probs - want).max() < 1e-5
+    gathered = [torch.empty_like(total) for _ in range(world)]
+    dist.all_gather(gathered, total)
+    assert all(torch.equal(gathered[0], t) for t in gathered)   # rank-ordered sum: bit-identical on every rank
+    np.save(os.path.join(tmp, f"okf_{rank}.npy"), np.array([1]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_fold_list_sharding(tmp_path, amd):
+    """The reference's fold list through partitioning B (driver :161): (fold, tile) items dealt over two ranks,
+    one rank-ordered exchange of the summed partial aggregates, fold mean = total / cnt / n_folds."""
+    par = amd.parallel
+    items = [par.shard_fold_tiles(5, 8, r, 3) for r in range(3)]
+    assert sorted(sum(items, [])) == [(f, t) for f in range(5) for t in range(8)]      # a partition of the work list
+    assert max(len(i) for i in items) - min(len(i) for i in items) <= 1               # balanced although 8 % 3 != 0
+    port = _free_port()
+    mp.spawn(_worker_folds, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"okf_{r}.npy").exists() for r in range(2))
+
+
 def _worker(rank, world, port, tmp):
     import sys
     sys.path.insert(0, ROOT)

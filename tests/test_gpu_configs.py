@@ -147,3 +147,25 @@ def test_bench_config4_under_the_launcher(gpu):
     assert out["config"]["cases"] == 2 and out["config"]["cases_per_rank"] == 2 and out["config"]["tiles_in_batch"] == 16
     assert out["value"] > 0 and out["roofline"]["kernel"].startswith("conv3_f16")
     assert sum(out["label_histogram"]) == 155 * 240 * 240
+
+
+def test_bench_config3_tile_sharded_under_the_launcher(gpu):
+    """`bench.py --config 3 --shard tiles` (SURVEY.md 8e partitioning B: ONE case, the (fold, tile) work list of each ensemble
+    member dealt over the ranks, one RCCL all_gather of the partial aggregates per member, strong scaling) exactly as the
+    driver would start it for N ranks - at N = 1, two folds per member, one step: a real `nccl` process group, the exchange on
+    the data path, the one-line JSON contract with "scaling": "strong"."""
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "3", "--shard", "tiles", "--folds", "2",
+           "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["steps"] == 1 and out["scaling"] == "strong" and out["dtype"] == "f16"
+    assert out["config"]["folds_per_member"] == 2 and out["config"]["sharding"].startswith("tiles")
+    assert out["value"] > 0 and sum(out["label_histogram"]) == 155 * 240 * 240

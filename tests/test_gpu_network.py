@@ -172,6 +172,31 @@ def test_fold_mean_and_tile_sharding(amd, gpu):
         assert torch.equal(parts[r][1], parts[0][1])  # every rank holds the same normaliser
 
 
+def test_fold_list_tile_sharding(amd, gpu):
+    """mi355_sw_partial_folds (SURVEY.md 8e partitioning B over the reference's fold list, driver :161): the (fold, tile) work
+    list of three folds x 2x2x2 tiles dealt over 1, 3 and 5 ranks; the rank-ordered sum of the partial aggregates, normalised
+    once and divided by the fold count, equals the fold mean of mi355_sw_predict (up to the fp32 rounding of the division
+    order) and the oracle's np.mean of per-fold predictions (driver :128)."""
+    sds = [_small_net(amd, seed=s) for s in (21, 22, 23)]
+    nets = [amd.UNet(sd, norm="batch") for sd in sds]
+    patch = (32, 32, 32)
+    vol = np.random.RandomState(8).standard_normal((4, 40, 48, 36)).astype(np.float32)
+    ref = np.mean([tiler_ref.predict_3d_tiled(tiler_ref.make_net_fn(sd, unet_ref.default_cfg("batch")), vol, patch, 3) for sd in sds], axis=0)
+    want = amd.predictor.predict_folds(nets, vol, patch)
+    assert amd.parallel.shard_fold_tiles(3, 8, 1, 5) == [(0, 1), (0, 6), (1, 3), (2, 0), (2, 5)]
+    for world in (1, 3, 5):
+        parts = [amd.predictor.predict_tile_sharded(nets, vol, r, world, patch) for r in range(world)]
+        agg = parts[0][0].clone()
+        for r in range(1, world):
+            agg += parts[r][0]
+            assert torch.equal(parts[r][1], parts[0][1])  # every rank holds the same one-fold normaliser
+        probs = amd.predictor.finish_sharded(agg, parts[0][1], vol.shape[1:], patch, n_folds=3)
+        assert float((probs - want).abs().max()) <= 2e-6, world
+        assert np.abs(probs.cpu().numpy() - ref).max() <= PROB_TOL
+    for n in nets:
+        n.close()
+
+
 # --------------------------------------------------------------------------- fp16 storage (BASELINE configs[2])
 # Tolerance for the fp16 path, stated here as the north_star asks: activations are rounded to fp16 (2^-11 relative)
 # after every block, accumulation stays fp32.  Against the fp32 CPU oracle we require the north_star's gate, Dice >= 0.999
@@ -397,20 +422,20 @@ def test_tta_full_tile_matches_oracle(amd, gpu, tile128, name, seed):
 
 
 def test_five_fold_mean_at_full_patch(amd, gpu, tile128):
-    """The reference's fold ensemble at the size it runs (run_brats2021_inference_singlethread.py:161 folds=(0, 1, 2, 3, 4),
-    :112-128: one prediction per fold, np.mean over them): five model-A folds (seeds 7..11, as bench.py's reference_setting
-    block) through predict_folds on one 128^3 volume (= one tile) against the mean of five CPU-oracle forwards, fp32 and fp16."""
+    """The reference's fold mean at the size it runs (run_brats2021_inference_singlethread.py:161 folds=(0, 1, 2, 3, 4),
+    :112-128: one prediction per fold, np.mean over them) WITHOUT the mirrors it also runs: five model-A folds (seeds 7..11)
+    through predict_folds on one 128^3 Gaussian-noise volume (= one tile) against the mean of five CPU-oracle forwards.
+    fp32 is gated at the north_star's tolerances.  For fp16 this is a DIAGNOSTIC of the least stable label map the suite can
+    produce, not the reference's setting (that is test_reference_fold_ensemble_with_tta below, gated at Dice >= 0.999): the
+    mean of five INDEPENDENT random-weight folds on a noise volume has its decision surface wherever the folds split 2 : 2,
+    and without the eight mirrors nothing averages the fp16 rounding down.  Measured (round 3): all-voxel Dice 0.99898,
+    probabilities within 8.0e-3.  Gated for fp16: probabilities within 2e-2 and Dice >= 0.9999 on the voxels whose reference
+    mean is at least 0.05 away from the threshold; the all-voxel Dice is printed."""
     sds = [amd.synthetic.make_model("A", seed=7 + k)[0] for k in range(5)]
     cfg = unet_ref.default_cfg(norm="batch")
     x = torch.from_numpy(tile128)
     ref = np.mean([torch.sigmoid(unet_ref.unet_forward(sd, x, cfg))[0].numpy() for sd in sds], axis=0)  # driver :128
-    # fp16 gate: the mean of five INDEPENDENT random-weight folds on a noise volume is the least stable label map this suite
-    # produces - wherever the folds split 2 : 2 the fifth decides, and one fold in five has its logit near zero somewhere
-    # in that voxel's neighbourhood - so the all-voxel Dice of the fp16 path reads 0.99898 here (measured, round 3; trained
-    # folds agree with each other, the bench's brain tile gives 0.99950-0.99987 per member).  Gates: probabilities within
-    # 2e-2 (measured 8.0e-3), all-voxel Dice >= 0.998, and >= 0.9999 on the voxels where the reference mean is at least
-    # 0.05 away from the threshold.
-    for dtype, tol, dice_min in (("f32", PROB_TOL, 0.9999), ("f16", 2e-2, 0.998)):
+    for dtype, tol in (("f32", PROB_TOL), ("f16", 2e-2)):
         nets = [amd.UNet(sd, norm="batch", dtype=dtype) for sd in sds]
         got = amd.predictor.predict_folds(nets, tile128[0], (128, 128, 128), 0.5, False, (0, 1, 2), True, "sigmoid").cpu().numpy()
         err = float(np.abs(got - ref).max())
@@ -418,10 +443,53 @@ def test_five_fold_mean_at_full_patch(amd, gpu, tile128):
         d = tiler_ref.brats_region_dice(lg, lr)
         sure = (np.abs(ref - 0.5) >= 0.05).all(0)
         d_sure = tiler_ref.brats_region_dice(lg[sure], lr[sure])
-        print(f"PARITY 5-fold mean 128^3 A {dtype}: prob err {err:.2e}, Dice {d['mean']:.6f} (clear voxels {d_sure['mean']:.6f})")
-        assert err <= tol and d["mean"] >= dice_min and d_sure["mean"] >= 0.9999
+        print(f"PARITY 5-fold mean 128^3 A {dtype} (no TTA): prob err {err:.2e}, Dice {d['mean']:.6f} (clear voxels {d_sure['mean']:.6f})")
+        assert err <= tol and d_sure["mean"] >= 0.9999
+        if dtype == "f32":
+            assert d["mean"] >= 0.9999
         for n in nets:
             n.close()
+
+
+@pytest.fixture(scope="module")
+def brain_block(amd, gpu):
+    """A 64 x 64 x 96 block of bench.py's synthetic brain volume (synthetic.make_volume(1000), cropped and z-scored on the
+    device): smooth tissue, part of the ellipsoid's surface and the exact zeros outside it."""
+    data, _ = amd.preprocessing.preprocess_case(amd.synthetic.make_volume(seed=1000), gpu)
+    return data[:, 40:104, 50:114, 0:96].contiguous().cpu().numpy()
+
+
+@pytest.mark.parametrize("name,seed0,shape", [("A", 7, (64, 64, 96)), ("B", 8, (64, 64, 64))])
+def test_reference_fold_ensemble_with_tta(amd, gpu, brain_block, name, seed0, shape):
+    """The fold ensemble AS THE REFERENCE RUNS IT (run_brats2021_inference_singlethread.py:161 folds=(0, 1, 2, 3, 4); :208-211
+    do_tta=True -> 8 mirrors; :112-128 one sliding-window prediction per fold, np.mean over the five), fp32 and fp16, against
+    the CPU oracle with the north_star's gate on ALL voxels: Dice >= 0.999 (fp32: probabilities within 1e-3 as well).
+    Sized for the suite: 64^3 patches (the smallest this topology takes) on a brain-like block - model A: 64 x 64 x 96 ->
+    two Gaussian-blended tiles, 80 oracle forwards; model B (GroupNorm-16, 3.5 x the flops): one tile, 40 forwards."""
+    data = np.ascontiguousarray(brain_block[:, :shape[0], :shape[1], :shape[2]])
+    patch = (64, 64, 64)
+    sds, meta = [], None
+    for k in range(5):
+        sd, meta = amd.synthetic.make_model(name, seed=seed0 + k)
+        sds.append(sd)
+    cfg = unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])
+    per_fold = [tiler_ref.predict_3d_tiled(tiler_ref.make_net_fn(sd, cfg), data, patch, 3, 0.5, True, (0, 1, 2), True, "sigmoid")
+                for sd in sds]
+    ref = np.mean(per_fold, axis=0)  # driver :128
+    lr = tiler_ref.regions_to_labels(ref)
+    assert lr.any(), "the block must contain foreground labels for the Dice to mean anything"
+    for dtype, tol in (("f32", PROB_TOL), ("f16", 2e-2)):
+        nets = [amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"], dtype=dtype) for sd in sds]
+        got = amd.predictor.predict_folds(nets, data, patch, 0.5, True, (0, 1, 2), True, "sigmoid").cpu().numpy()
+        for n in nets:
+            n.close()
+        err = float(np.abs(got - ref).max())
+        lg = tiler_ref.regions_to_labels(got)
+        d = tiler_ref.brats_region_dice(lg, lr)
+        print(f"PARITY reference setting (5 folds x 8 mirrors, fold mean) {name} {dtype}: prob err {err:.2e}, "
+              f"{int((lg != lr).sum())} of {lr.size} labels differ, Dice WT/TC/ET {d['WT']:.6f} {d['TC']:.6f} {d['ET']:.6f} mean {d['mean']:.6f}")
+        assert err <= tol, (dtype, err)
+        assert d["mean"] >= 0.999 and min(d["WT"], d["TC"], d["ET"]) >= 0.999, (dtype, d)   # north_star, un-lowered
 
 
 @pytest.fixture(scope="module")

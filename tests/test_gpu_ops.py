@@ -294,6 +294,25 @@ def test_tconv_f16_matches_torch(amd, gpu, case):
     assert np.abs(y - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("case", [(1, 33, 63, 65, 32, 32), (2, 32, 32, 64, 64, 32), (1, 32, 64, 64, 128, 64)])
+def test_tconv_f16_persistent_kernel_matches_torch(amd, gpu, case):
+    """the persistent tconv2_f16_mfma_v3_kernel (every fp16 decoder level with Cin 32 / 64 / 128 and >= 1024 tiles of
+    128 input voxels) had no single-op case - the shapes above dispatch to v2.  These have >= 131072 input voxels, one of them
+    ragged (33 x 63 x 65 = 135135 voxels, not a multiple of 128: the clamped tail tile and its store predicate), and assert
+    that v3 is the kernel that ran."""
+    n, d, h, w, cin, cout = case
+    rs = np.random.RandomState(15)
+    x = _rand(rs, n, d, h, w, cin).astype(np.float16)
+    wt = (_rand(rs, cin, cout, 2, 2, 2) / np.sqrt(cin)).astype(np.float16)
+    ref = F.conv_transpose3d(torch.from_numpy(x.astype(np.float32)).permute(0, 4, 1, 2, 3),
+                             torch.from_numpy(wt.astype(np.float32)), None, stride=2)
+    ref = ref.permute(0, 2, 3, 4, 1).contiguous().numpy()
+    y = amd.ops.tconv3d_ndhwc(torch.from_numpy(x).to(gpu), wt.astype(np.float32)).float().cpu().numpy()
+    assert amd.ops.last_conv_kernel().startswith("tconv2_f16_mfma_v3_kernel<"), amd.ops.last_conv_kernel()
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("shape,seed", [((155, 240, 240), 1000), ((40, 56, 48), 5), ((33, 17, 29), 6)])
 def test_crop_mask_matches_scipy_fill_holes(amd, gpu, shape, seed):
     """crop_to_nonzero on the device (nonzero mask, hole filling by border flood fill, bounding box): bit-exact against the

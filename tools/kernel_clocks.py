@@ -9,9 +9,11 @@ over the launches of a kernel.  This is the clock the chip actually granted whil
 turns "fraction of the nominal 2.5 PFLOP/s (at 2.4 GHz)" into "fraction of what the clock allowed".  Launches shorter than
 50 us are left out (timestamp granularity).
 
-    python tools/kernel_clocks.py profiles/r03_pmc_sq_f16.csv profiles/r03_pmc_sq_f32.csv [--json profiles/kernel_clocks.json]
+    python tools/kernel_clocks.py config3_f16=profiles/r04_pmc_sq_f16.csv config2_f32=profiles/r04_pmc_sq_f32.csv \
+        [--json profiles/kernel_clocks.json] [--digest <sha>]
 
---json writes {kernel: {"shader_clock_ghz": .., "launches": .., "avg_ms": .., "source": csv}} for bench.py's roofline block.
+--json writes {section: {kernel: {"shader_clock_ghz": .., "launches": .., "avg_ms": .., "source": csv}}} for bench.py's roofline
+block (sections = workloads, as profiles/pmc_traffic.json) and the digest of the library the passes ran on.
 """
 import collections
 import csv
@@ -37,8 +39,15 @@ def main():
         i = args.index("--json")
         out_json = args[i + 1]
         del args[i:i + 2]
+    digest = None
+    if "--digest" in args:
+        i = args.index("--digest")
+        digest = args[i + 1]
+        del args[i:i + 2]
     table = {}
-    for path in args:
+    for spec in args:
+        section, path = spec.split("=", 1) if "=" in spec else ("", spec)
+        sec = table.setdefault(section, {}) if section else table
         acc = collections.defaultdict(lambda: [0.0, 0.0, 0])
         for r in csv.DictReader(open(path, newline="")):
             if r["Counter_Name"] != "GRBM_GUI_ACTIVE":
@@ -52,11 +61,12 @@ def main():
         print(f"  {'kernel':62s} launches   avg ms   shader clock")
         for k, (cyc, ns, n) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
             print(f"  {k[:62]:62s} {n:8d} {ns / n / 1e6:8.3f}   {cyc / 8 / ns:5.2f} GHz")
-            table[k] = dict(shader_clock_ghz=round(cyc / 8 / ns, 3), launches=n, avg_ms=round(ns / n / 1e6, 4), source=path)
+            sec[k] = dict(shader_clock_ghz=round(cyc / 8 / ns, 3), launches=n, avg_ms=round(ns / n / 1e6, 4), source=path)
     if out_json:
         table["_method"] = ("rocprofv3 --pmc ... GRBM_GUI_ACTIVE passes of `python3 bench.py --steps 1 --warmup 0 --no-secondary --no-cpu-baseline` "
                             "(config 2 f32 / config 3 f16, tools/collect_profiles.sh): sum(GRBM_GUI_ACTIVE) / 8 XCDs / sum(dispatch end - start), "
                             "launches >= 50 us, tools/kernel_clocks.py")
+        table["_source_digest"] = digest
         json.dump(table, open(out_json, "w"), indent=1, sort_keys=True)
 
 

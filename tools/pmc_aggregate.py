@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Turns rocprofv3 --pmc counter CSVs into profiles/pmc_traffic.json (what bench.py reports as roofline.traffic).
 
-    python tools/pmc_aggregate.py --fetch <..._counter_collection.csv> --write <..._counter_collection.csv> \
-        [--fetch ... --write ... for a second dtype] --out profiles/pmc_traffic.json --note "..."
+    python tools/pmc_aggregate.py --section config2_f32 --fetch <..._counter_collection.csv> --write <..._counter_collection.csv> \
+        [--section ... --fetch ... --write ... for another workload] --out profiles/pmc_traffic.json --note "..." --digest <sha>
+
+One section per workload (bench.py asks for "config2_f32", "config3_f16", "config3_f32": the same kernel has other launch
+sizes in another workload).  --digest = the source digest of the library the passes ran on (lib/libmi355_nnunet.so.digest on
+the GPU box); bench.py compares it with the running library's and reports `traffic_stale`.
 
 Per kernel: the mean over its launches of FETCH_SIZE and WRITE_SIZE (KiB), and
 hbm_bytes_per_launch = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024.  FETCH_SIZE is doubled because gfx950 tallies
@@ -52,23 +56,28 @@ def read(path, counter):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--section", action="append", required=True)
+    ap.add_argument("--digest", default=None)
     ap.add_argument("--fetch", action="append", required=True)
     ap.add_argument("--write", action="append", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--note", default="")
     args = ap.parse_args()
-    out = {"_method": args.note}
-    for fpath, wpath in zip(args.fetch, args.write):
+    out = {"_method": args.note, "_source_digest": args.digest}
+    n = 0
+    for sec, fpath, wpath in zip(args.section, args.fetch, args.write):
         f, w = read(fpath, "FETCH_SIZE"), read(wpath, "WRITE_SIZE")
+        tab = out.setdefault(sec, {})
         for k in f:
-            if k.startswith("__amd") or k not in w or k in out:
+            if k.startswith("__amd") or k not in w:
                 continue
             fk, wk = f[k][1] / f[k][0], w[k][1] / w[k][0]
-            out[k] = {"launches": f[k][0], "FETCH_SIZE_KiB_per_launch": round(fk, 1), "WRITE_SIZE_KiB_per_launch": round(wk, 1),
+            tab[k] = {"launches": f[k][0], "FETCH_SIZE_KiB_per_launch": round(fk, 1), "WRITE_SIZE_KiB_per_launch": round(wk, 1),
                       "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024)}
+            n += 1
     with open(args.out, "w") as fh:
         json.dump(out, fh, indent=1)
-    print(f"{args.out}: {len(out) - 1} kernels")
+    print(f"{args.out}: {n} kernel entries in {len(args.section)} sections")
 
 
 if __name__ == "__main__":
