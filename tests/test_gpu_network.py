@@ -64,15 +64,20 @@ def test_instance_and_group_norm_forwards_are_bit_reproducible(amd, gpu):
         net.close()
 
 
+SMALL_ACT_TOL = {"A_in": 1.5e-4, "B": 2.5e-5}
+
+
 @pytest.mark.parametrize("name", ["A_in", "B"])
 def test_norm_statistics_of_small_activations(amd, gpu, name):
     """the Instance/GroupNorm partial sums are rounded to a fixed quantum before the atomic add (common.h,
     quantise_partial).  Round 2's quantum for sum x^2 was 2e-3 at a 128^3 patch: with every conv weight scaled by 2e-3 the
     pre-norm activations have rms ~1e-3..1e-2, a workgroup's partial (128-512 voxels) lies at or below that quantum and
     the variance came out coarse or zero, i.e. a wrong 1/sqrt(var + eps) where var ~ eps.  The reference computes exact
-    fp32 statistics (generic_UNet.py:43,62-65).  Gate: 3e-4 x logit spread.  With var ~ eps the normalisation no longer
-    restores unit scale, the logits of the scaled net are small (spread 1.6 / 8.1) and ordinary fp32 summation noise is
-    1.1e-4 of it (measured, round 3, with exact statistics); a statistics error of the kind guarded against moves
+    fp32 statistics (generic_UNet.py:43,62-65).  With var ~ eps the normalisation no longer restores unit scale, the logits of
+    the scaled net are small (spread 1.3-2.1 for A_in, 1.9-8.1 for B) and ordinary fp32 summation noise is a larger fraction of
+    it than in the other cases of this file.  Gates re-derived in round 4 from 3 model seeds x 3 input seeds each
+    (tests/diagnostics/gate_seeds.py, profiles/r04_gate_seeds.txt): A_in 3.8e-5 .. 9.2e-5 x spread (this case: 6.7e-5), B
+    2.3e-6 .. 1.07e-5; gate = 1.6 x / 2.3 x the largest of the nine.  A statistics error of the kind guarded against moves
     1 / sqrt(var + eps) by 2-50 % and the logits by > 1e-2 of their spread."""
     sd, meta = amd.synthetic.make_model(name, seed=7)
     sd = {k: (v * 2e-3 if k.endswith(".conv.weight") else v) for k, v in sd.items()}
@@ -81,7 +86,7 @@ def test_norm_statistics_of_small_activations(amd, gpu, name):
     ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])).numpy()
     got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
     assert float(ref.std()) > 1e-3, "the scaled net must still produce a signal"
-    _check_logits(got, ref, f"64^3 {name} with pre-norm rms ~1e-3", rel_tol=3e-4)
+    _check_logits(got, ref, f"64^3 {name} with pre-norm rms ~1e-3", rel_tol=SMALL_ACT_TOL[name])
     net.close()
 
 
@@ -281,7 +286,10 @@ np.savez(sys.argv[1], y=y, names=np.array(names))
     spread = float(plain["y"].std())
     err = float(np.abs(fused["y"] - plain["y"]).max())
     print(f"PARITY fused-vs-separate norm (f16, B 64^3): {err / spread:.2e} x spread")
-    assert err <= 2e-2 * spread  # (measured 8.5e-3: what any 2^-11 perturbation of an early activation grows to; each build is within 2.3e-2 of the oracle)
+    # gate re-derived in round 4 from four input seeds (tests/diagnostics/gate_seeds.py, profiles/r04_gate_seeds.txt): 7.7e-3, 7.7e-3,
+    # 8.4e-3, 8.4e-3 x spread (this seed: 8.4e-3) - what any 2^-11 perturbation of an early activation grows to; each build is
+    # within 6.9e-3 .. 8.2e-3 of the oracle on the same inputs.  1.2e-2 = 1.4 x the largest of the four.
+    assert err <= 1.2e-2 * spread
 
 
 def test_sliding_window_f16_tta(amd, gpu):
