@@ -1612,6 +1612,11 @@ int conv_weights_upload(const float *w_host, const float *bias_host, int cin, in
                 else pack_conv_weights_wino(w_host, cin, cin_pad, cout, packed);
                 MI355_HIP(hipMalloc(&cw.wpw_dev, packed.size() * sizeof(float)));
                 MI355_HIP(hipMemcpy(cw.wpw_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+                if (cw.wino2 && conv3d_wino3_enabled()) {  // F(2x2x2, 3x3x3): the launches that are whole 4 x 8 x 8 tiles (conv3d_wino3.hip)
+                    pack_conv_weights_wino3(w_host, cin, cin_pad, cout, packed);
+                    MI355_HIP(hipMalloc(&cw.wp3_dev, packed.size() * sizeof(float)));
+                    MI355_HIP(hipMemcpy(cw.wp3_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+                }
             }
         }
     }
@@ -1638,6 +1643,7 @@ void conv_weights_free(ConvWeights *w) {
     if (w->wp_dev) (void)hipFree(w->wp_dev);
     if (w->wp16_dev) (void)hipFree(w->wp16_dev);
     if (w->wpw_dev) (void)hipFree(w->wpw_dev);
+    if (w->wp3_dev) (void)hipFree(w->wp3_dev);
     if (w->bias_dev) (void)hipFree(w->bias_dev);
     if (w->w_plain_dev) (void)hipFree(w->w_plain_dev);
     *w = ConvWeights();
@@ -1724,6 +1730,11 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
     a.nchunks = w.cin_pad / w.cc;
     a.act = c.act; a.slope = c.slope;
     a.ksplit = 1; a.partial = nullptr; a.zero_bias = nullptr; a.out_elems = 0;
+    if (w.wp3_dev) {
+        bool taken = false;
+        MI355_TRY(conv3d_wino3_f32(w, c, s, kernel_name, &taken));
+        if (taken) return MI355_OK;
+    }
     if (w.wpw_dev) {
         // auto mode, large launches: Winograd F(2,3) along y on fixed 4x4x32 tiles, 32 couts per workgroup
         ConvArgs b = a;

@@ -1,0 +1,575 @@
+// 3x3x3 convolution, stride 1, NDHWC fp32, as Winograd F(2x2x2, 3x3x3) on the gfx950 matrix cores (round 4).
+//
+// Replaces torch.nn.Conv3d(k=3, p=1) of ConvDropoutNormNonlin (reference model_architecture/generic_UNet.py:56,69) on the
+// large stride-1 layers of the fp32 path.  gfx950 has no TF32: an f32 MFMA is an exact fmaf chain at 157 TFLOP/s, so the
+// lever of the fp32 path is the NUMBER of multiplies.  conv3_f32_wino2_kernel (conv3d.hip) transforms (z, y) and walks x
+// directly: 4 * 4 * 3 = 48 multiplies per 2x2 outputs and x tap set, i.e. 4/9 of the direct count.  Here all three axes
+// are transformed: a 2x2x2 output block costs 4 * 4 * 4 = 64 multiplies per (cin, cout) instead of 8 * 27 = 216 - 8/27 of
+// the direct count, two thirds of the 2-D kernel's.
+//
+// Mapping.  Workgroup = 4 waves = one tile of 32 output blocks (2 x 4 x 4 blocks = 4 x 8 x 8 voxels) x 32 couts.  The 64
+// transform-domain components are dealt over the waves by their z index: wave w owns xi_z = w and its 16 (xi_y, xi_x)
+// components, 16 accumulator fragments of 32 couts x 32 blocks = 256 AGPRs - one wave per SIMD, one persistent workgroup
+// per CU, the skeleton of the 2-D kernel:
+//   * MFMA v_mfma_f32_32x32x2_f32, A = transformed weights U[xi][cout][cin pair], B = transformed input V[xi][cin pair][block];
+//     a lane is a block (lane & 31) and a channel pair of the current quad (lane >> 5);
+//   * the 16-channel halo brick (6 x 10 x 10 voxels) is double-buffered in LDS and filled by LDS-DMA
+//     (global_load_lds_dwordx4; out-of-volume voxels read a zero page).  Slots are 16 B = one channel quad of a voxel,
+//     ordered [quad][z][y][x parity][x / 2]: a lane's four x taps are then two adjacent slots per parity and the 32 blocks
+//     of a half-wave read 32 different slots whose bank groups tile the 64 banks exactly twice (the minimum for 8-B reads);
+//   * a step = one channel quad: 32 reads of 8 B (two z planes x 4 x 4 positions), V = B^T d B as 16 + 16 + 16 packed
+//     operations (the z stage is one fma with a per-wave sign: xi_z = 0..3 are d0 - d2, d1 + d2, d2 - d1, d1 - d3), 32 MFMAs;
+//     reads, transform, weight loads and brick DMAs of the NEXT step are dealt out between the MFMAs of the current one;
+//   * epilogue: every wave applies A^T along y and x to its 16 components (16 -> 4 values per cout), writes the four partial
+//     images to an LDS staging area [wave][oy, ox][block][cout], and after one barrier wave (oy, ox) adds the four xi_z
+//     partials with A^T along z (out0 = p0 + p1 + p2, out1 = p1 - p2 - p3), applies bias / LeakyReLU and stores whole
+//     128-B lines (8 lanes x 16 B = the 32 couts of one voxel).
+// Numerics: U = G w G^T per axis in fp64, rounded once; tests/diagnostics/wino3d_numerics.py (CPU emulation of the whole
+// network, sequential fp32 accumulation chains) gives a smaller logit error than the 2-D form (shorter chains: K = Cin
+// per component instead of 3 Cin).
+#include "kernels.h"
+
+#include <cstdlib>
+#include <vector>
+
+// (the brick DMA below names m0 in its clobber list: it is a reserved register, which clang reports; nothing else in these kernels uses it)
+#pragma clang diagnostic ignored "-Winline-asm"
+
+namespace mi355 {
+
+struct Wino3Args {
+    const float *in0, *in1;
+    const float *wp, *bias;
+    float *out;
+    double *stats;
+    int C0, C1, N, D, H, W, Cout, nchunks, act;
+    float slope;
+    int total_tiles;
+    FastDiv div_tiles_per_n;
+    TileOrder order;
+    const float *zeros;  // >= 64 B of zeros in global memory: the source of every out-of-volume piece
+    const float *head_w, *head_b;
+    float *head_out;
+    int head_ncls;
+};
+
+#ifdef MI355_W3_STAMPS
+// Diagnostic build only (tools/wino3_probe.hip): cycle sums per phase, wave 0 of every workgroup.
+// Slots: 0 chunk prologue, 1 step loop, 2 chunk drain + barrier, 3 epilogue phase 1 (in-wave output transform), 4 whole epilogue,
+// 5 kernel, 6 chunks, 7 tiles, 9 accumulator reset, 10 whole chunk body (steps 0-3 + barrier).
+__device__ unsigned long long w3_stamps[1024 * 16];
+#define W3_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define W3_ACC(slot, a, b) do { if (threadIdx.x == 0) w3_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] += (b) - (a); } while (0)
+#define W3_CNT(slot) do { if (threadIdx.x == 0) w3_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] += 1; } while (0)
+#else
+#define W3_T(var)
+#define W3_ACC(slot, a, b)
+#define W3_CNT(slot)
+#endif
+#ifndef MI355_W3_ABL
+#define MI355_W3_ABL 0  // ablation bits (probe only, results wrong): 1 no epilogue, 4 no brick DMA, 8 no weight loads, 16 no input transform, 32 no stores
+#endif
+
+constexpr int W3_IZ = 6, W3_IY = 10, W3_IX = 10, W3_BV = W3_IZ * W3_IY * W3_IX;  // 600 brick voxels
+constexpr int W3_PS = 640;                      // slots per quad plane: 10 DMA ranges of 64
+constexpr int W3_BUF = 4 * W3_PS * 4;           // floats per brick buffer (4 quad planes)
+constexpr int W3_PITCH = 36;                    // floats per staged block row (128 B + 16 B)
+constexpr int W3_IMG = 32 * W3_PITCH;           // one staged image: 32 blocks x 32 couts
+constexpr int W3_STAGE = 4 * 4 * W3_IMG;        // [wave = xi_z][oy, ox][block][cout]
+constexpr int W3_JUNK = 64 * 4;                 // destination of the dummy DMAs that keep the per-wave DMA count uniform
+constexpr size_t W3_LDS_BYTES = (size_t)(2 * W3_BUF + W3_STAGE + W3_JUNK + 4 * 32 * 2) * sizeof(float);
+static_assert(W3_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+// EPI: 0 = bias + LeakyReLU + store, 2 = the same + Instance/GroupNorm statistics (sum x, sum x^2 per sample and cout)
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int STEPS = 4;  // channel quads per 16-channel chunk
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int bx = l31 & 3, by = (l31 >> 2) & 3, bz = l31 >> 4;
+    float *stage = lds + 2 * W3_BUF;
+    float *junk = stage + W3_STAGE;
+    float *red = junk + W3_JUNK;
+
+    // tile sequence of this workgroup: XCD group x owns one contiguous range of tile ids
+    const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x - xcd + 7) >> 3;
+    const int q8 = p.total_tiles >> 3, r8 = p.total_tiles & 7;
+    const int lo = xcd * q8 + (xcd < r8 ? xcd : r8);
+    const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
+    int tile = lo + li;
+    if (tile >= hi) return;
+
+    struct TileCoord { int n, oz0, oy0, ox0; };
+    auto decode = [&](int t) {
+        TileCoord tc;
+        tc.n = (int)fdiv((uint32_t)t, p.div_tiles_per_n);
+        const int tt = t - tc.n * (int)p.div_tiles_per_n.d;
+        int tx, ty, tz;
+        tile_from_id(tt, p.order, tx, ty, tz);
+        tc.oz0 = tz << 2; tc.oy0 = ty << 3; tc.ox0 = tx << 3;
+        return tc;
+    };
+
+    // brick DMA: range r = 64 consecutive slots of every quad plane; wave w issues ranges w, w + 4, w + 8 (the last one only
+    // exists for waves 0 and 1: the others send theirs to a junk area from the zero page, so that every wave has the same
+    // number of vector-memory operations in flight and the hand-counted waits below hold for all four)
+    unsigned dma_pk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int v = (wave + 4 * k) * 64 + lane;
+        const int pad = v >= W3_BV ? 1 : 0;
+        const int vv = pad ? 0 : v;
+        const int rz = vv / 100, rem = vv - rz * 100;
+        const int ry = rem / 10, r2 = rem - ry * 10;
+        const int par = r2 / 5, xh = r2 - par * 5;
+        dma_pk[k] = (unsigned)(rz | (ry << 4) | ((2 * xh + par) << 8) | (pad << 16));
+    }
+    auto dma_group = [&](const TileCoord &tc, int ch, int k, float *buf) {
+        const int rng = wave + 4 * k;
+        const bool dummy = rng >= 10;  // scalar
+        const int cglob = ch * 16;
+        const float *src; int Csrc, coff;
+        if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
+        else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
+        src += ((((size_t)tc.n * p.D + (tc.oz0 - 1)) * p.H + (tc.oy0 - 1)) * p.W + (tc.ox0 - 1)) * (long)Csrc + coff;
+        unsigned pk = dma_pk[k];
+        asm volatile("" : "+v"(pk));  // unpack here, every time (hoisted out of the tile loop the fields get spilled)
+        const int rz = pk & 15, ry = (pk >> 4) & 15, rx = (pk >> 8) & 15, pad = pk >> 16;
+        const bool in_vol = !pad && !dummy && ((unsigned)(tc.oz0 - 1 + rz) < (unsigned)p.D) && ((unsigned)(tc.oy0 - 1 + ry) < (unsigned)p.H) &&
+                            ((unsigned)(tc.ox0 - 1 + rx) < (unsigned)p.W);
+        const int voff = ((rz * p.H + ry) * p.W + rx) * Csrc;
+        const float *g = in_vol ? src + voff : p.zeros;
+        asm volatile("" : "+v"(g));  // one DMA per quad for every lane (a branchy select would break the vmcnt count)
+        // the instruction's immediate offset is added to the global AND the LDS address: the LDS base of quad Q is moved back by it
+        float *dst = dummy ? junk : buf + rng * 64 * 4;
+        const int qs = dummy ? -4 : (W3_PS * 4 - 4);
+        // Inline asm, not __builtin_amdgcn_global_load_lds: hipcc tracks the builtin's LDS writes and, wherever it cannot prove that a
+        // ds_read does not alias one in flight - at every loop back edge - it retires ALL vector memory operations (vmcnt(0)) in front
+        // of the read.  This pipeline keeps a DMA group in flight across the chunk loop's back edge by design (the barrier that
+        // publishes the data is what orders it), and the wait cost 650 cycles per chunk (tools/wino3_probe stamps).  M0 = LDS byte
+        // address of lane 0's slot; one wait state between the write of M0 and its use.
+        const unsigned m0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)dst;
+#define W3_DMA(Q)                                                                                                         \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%2"                                \
+                 :: "s"(m0 + (unsigned)((Q) * qs * 4)), "v"(g), "n"((Q) * 16) : "memory", "m0")
+        W3_DMA(0);
+        W3_DMA(1);
+        W3_DMA(2);
+        W3_DMA(3);
+#undef W3_DMA
+    };
+
+    // this lane's block origin in the brick (slot of (2 bz, 2 by, 2 bx)), floats, + its channel pair; the two z planes of the
+    // wave's component: xi_z = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3  ->  T = dA + sgn * dB
+    const int a_base = (((2 * bz) * W3_IY + 2 * by) * W3_IX + bx) * 4 + half * 2;
+    const int zA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), zB = wave == 2 ? 1 : (wave == 3 ? 3 : 2);
+    const float sgn = wave == 1 ? 1.0f : -1.0f;
+    const int offA = a_base + zA * (W3_IY * W3_IX * 4), offB = a_base + zB * (W3_IY * W3_IX * 4);
+
+    // packed U: [cout block][chunk][quad][xi_z][fragment pair 0..7][lane][f & 1][j]: one 16-B load per lane = fragments 2k, 2k + 1.
+    // Inline asm with hand-counted waits (conv3d.hip: with an LDS-DMA in flight hipcc retires every vector-memory operation
+    // before the first use of an ordinary load).
+    const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (STEPS * 4 * 2048) + wave * 2048;
+    const unsigned wl0 = lane * 16, wl1 = lane * 16 + 4096;
+#define W3_ULOAD(DST, VOFF, SBASE, IMM) \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(DST) : "v"(VOFF), "s"(SBASE), "n"(IMM) : "memory")
+#define W3_UWAIT(U, N)                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                             \
+                 : "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(U[3]), "+v"(U[4]), "+v"(U[5]), "+v"(U[6]), "+v"(U[7])      \
+                 :                                                                                                     \
+                 : "memory")
+
+    auto pk_add = [](f32x2 x, f32x2 y) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    auto pk_sub = [](f32x2 x, f32x2 y) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    // position pos = iy * 4 + ix of the 4 x 4 patch: slot offset iy * IX + (ix & 1) * 5 + (ix >> 1)
+    auto slot_of = [](int pos) { return ((pos >> 2) * W3_IX + ((pos & 1) * 5) + ((pos & 3) >> 1)) * 4; };
+    // reads of one half of the patch (8 positions x 2 planes) of quad q from buffer b
+    auto read8 = [&](const float *b, int q, int hb, f32x2 (&dA)[8], f32x2 (&dB)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dA[i] = *(const f32x2 *)(b + offA + q * (W3_PS * 4) + slot_of(hb * 8 + i));
+            dB[i] = *(const f32x2 *)(b + offB + q * (W3_PS * 4) + slot_of(hb * 8 + i));
+        }
+    };
+    const f32x2 sg2 = {sgn, sgn};
+    auto z_op = [&](const f32x2 (&dA)[8], const f32x2 (&dB)[8], f32x2 (&T)[16], int hb) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x2 r;
+            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(dB[i]), "v"(sg2), "v"(dA[i]));
+            T[hb * 8 + i] = r;
+        }
+    };
+    // y stage for x column ix: T[iy][ix] -> Y[xi_y][ix]
+    auto y_op = [&](const f32x2 (&T)[16], f32x2 (&Y)[16], int ix) {
+        Y[0 * 4 + ix] = pk_sub(T[0 * 4 + ix], T[2 * 4 + ix]);
+        Y[1 * 4 + ix] = pk_add(T[1 * 4 + ix], T[2 * 4 + ix]);
+        Y[2 * 4 + ix] = pk_sub(T[2 * 4 + ix], T[1 * 4 + ix]);
+        Y[3 * 4 + ix] = pk_sub(T[1 * 4 + ix], T[3 * 4 + ix]);
+    };
+    // x stage for row xi_y: Y[xi_y][ix] -> V[xi_y * 4 + xi_x]
+    auto x_op = [&](const f32x2 (&Y)[16], f32x2 (&V)[16], int fy) {
+        V[fy * 4 + 0] = pk_sub(Y[fy * 4 + 0], Y[fy * 4 + 2]);
+        V[fy * 4 + 1] = pk_add(Y[fy * 4 + 1], Y[fy * 4 + 2]);
+        V[fy * 4 + 2] = pk_sub(Y[fy * 4 + 2], Y[fy * 4 + 1]);
+        V[fy * 4 + 3] = pk_sub(Y[fy * 4 + 1], Y[fy * 4 + 3]);
+    };
+
+    // Pipeline (one barrier per chunk, nothing exposed but the very first transform of the kernel):
+    //   chunk c, steps 0 1 2: MFMAs of quads 0 1 2; between them the transform of the next quad (from brick buffer c), the next
+    //                         step's weights and - steps 0 and 1 - DMA groups 1 and 2 of chunk c + 1 into the other buffer;
+    //   [vmcnt(0) + barrier]: chunk c + 1 is in LDS for everybody, buffer c is no longer read by anybody;
+    //   step 3:               MFMAs of quad 3; between them the transform of quad 0 of chunk c + 1 (from the other buffer),
+    //                         the weights of that step, and DMA group 0 of chunk c + 2 into buffer c.
+    // The brick DMA therefore runs as its own stream of (tile, chunk) positions, one chunk ahead of the MFMAs and across tile
+    // boundaries; past the last chunk it re-stages the last one (nobody reads it), so the wait counts stay fixed.
+    W3_T(t_kernel0);
+    TileCoord cur = decode(tile);
+    TileCoord d_tc = cur;
+    int d_tile = tile, d_ch = 0;
+    auto d_advance = [&]() {
+        if (d_ch + 1 < p.nchunks) { ++d_ch; return; }
+        if (d_tile + nl < hi) { d_tile += nl; d_tc = decode(d_tile); d_ch = 0; }
+    };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dma_group(d_tc, d_ch, k, lds);
+    f32x4 uq[2][8];
+    static_for<0, 8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        auto &u0 = uq[0]; const unsigned wl = k < 4 ? wl0 : wl1; const float *wb = wblk;
+        W3_ULOAD(u0[k], wl, wb, (k & 3) * 1024);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x2 dA[8], dB[8], T[16], Y[16], V[2][16];
+    {   // the first transform of the kernel (exposed once)
+        read8(lds, 0, 0, dA, dB);
+        z_op(dA, dB, T, 0);
+        read8(lds, 0, 1, dA, dB);
+        z_op(dA, dB, T, 1);
+#pragma unroll
+        for (int ix = 0; ix < 4; ++ix) y_op(T, Y, ix);
+#pragma unroll
+        for (int fy = 0; fy < 4; ++fy) x_op(Y, V[0], fy);
+    }
+    d_advance();
+    dma_group(d_tc, d_ch, 0, lds + W3_BUF);  // ("step 3 of chunk -1")
+    {   // (the first tile's first step has no weight wait of its own: retire uq[0] here, behind the DMA group - once per kernel)
+        auto &u0 = uq[0];
+        W3_UWAIT(u0, 0);
+    }
+
+    int buf = 0;
+    for (; tile < hi; tile += nl) {
+        W3_T(t_t0);
+        f32x16 acc[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+        const int ntile = tile + nl;
+        const TileCoord nxt_tile = ntile < hi ? decode(ntile) : cur;
+        W3_T(t_t1);
+        W3_ACC(9, t_t0, t_t1);
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const bool last_ch = ch == p.nchunks - 1;
+            const float *bufc = lds + buf * W3_BUF;
+            float *bufn = lds + (buf ^ 1) * W3_BUF;
+            const float *wch = wblk + (size_t)ch * (STEPS * 4 * 2048);
+            const float *wnx = wblk + (size_t)(last_ch ? 0 : ch + 1) * (STEPS * 4 * 2048);
+            W3_T(t_c1);
+            static_for<0, STEPS>([&](auto st_c) {
+                constexpr int st = decltype(st_c)::value;
+                constexpr int pp = st & 1;
+                auto &uc = uq[pp];
+                // this step's weights: everything older than the 4 brick DMAs the previous step issued behind them.  A tile's first
+                // step finds its weights retired already (the epilogue waits for them before its stores); step 3 follows the
+                // chunk barrier's vmcnt(0)
+                if constexpr (st == 0) { if (ch != 0) W3_UWAIT(uc, 4); }
+                else if constexpr (st < 3) W3_UWAIT(uc, 4);
+                else W3_UWAIT(uc, 0);
+                const float *wn = (st + 1 < STEPS) ? wch + (size_t)(st + 1) * (4 * 2048) : wnx;
+                const float *rb = (st + 1 < STEPS) ? bufc : bufn;   // brick the next quad is read from
+                constexpr int rq = (st + 1) & 3;
+                static_for<0, 32>([&](auto i_c) {
+                    constexpr int i = decltype(i_c)::value;
+                    constexpr int f = i & 15, j = i >> 4;
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(uq[pp][f >> 1][(f & 1) * 2 + j], V[pp][f][j], acc[f], 0, 0, 0);
+                    if constexpr ((MI355_W3_ABL & 16) == 0) {
+                        // V of the next quad, dealt over the MFMA gaps in bunches (a gap that holds VALU work costs the matrix
+                        // pipe ~5 cycles + ~4.4 per instruction, tools/coissue_probe.hip)
+                        if constexpr (i == 0) read8(rb, rq, 0, dA, dB);
+                        if constexpr (i == 6) z_op(dA, dB, T, 0);
+                        if constexpr (i == 7) read8(rb, rq, 1, dA, dB);
+                        if constexpr (i == 13) z_op(dA, dB, T, 1);
+                        if constexpr (i == 14) { y_op(T, Y, 0); y_op(T, Y, 1); }
+                        if constexpr (i == 15) { y_op(T, Y, 2); y_op(T, Y, 3); }
+                        if constexpr (i == 17) { x_op(Y, V[pp ^ 1], 0); x_op(Y, V[pp ^ 1], 1); }
+                        if constexpr (i == 18) { x_op(Y, V[pp ^ 1], 2); x_op(Y, V[pp ^ 1], 3); }
+                    }
+                    if constexpr (i < 16 && (i & 1) == 0) {  // the next step's weights - unconditionally: a branch per load would cut
+                        constexpr int k = i >> 1;            // the MFMA stream into basic blocks.  A tile's last step fetches the next
+                        auto &un = uq[pp ^ 1]; const unsigned wl = k < 4 ? wl0 : wl1; const float *wb = wn;  // tile's first fragments
+                        if constexpr ((MI355_W3_ABL & 8) == 0) W3_ULOAD(un[k], wl, wb, (k & 3) * 1024);      // (same cout block, chunk 0)
+                    }
+                    if constexpr ((MI355_W3_ABL & 4) == 0 && i == 20) {
+                        if constexpr (st == 0) dma_group(d_tc, d_ch, 1, bufn);
+                        if constexpr (st == 1) { dma_group(d_tc, d_ch, 2, bufn); d_advance(); }
+                        if constexpr (st == 3) dma_group(d_tc, d_ch, 0, const_cast<float *>(bufc));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (st == 2) {
+                    W3_T(t_c2);
+                    W3_ACC(1, t_c1, t_c2);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier
+                    __syncthreads();
+                    W3_T(t_c3);
+                    W3_ACC(2, t_c2, t_c3);
+                }
+            });
+            W3_T(t_c4);
+            W3_ACC(10, t_c1, t_c4);
+            buf ^= 1;
+            W3_CNT(6);
+        }
+        W3_T(t_e0);
+        if constexpr ((MI355_W3_ABL & 1) != 0) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f) asm volatile("" :: "a"(acc[f]));
+        } else {
+            // ---- phase 1: A^T along y and x inside the wave (16 components -> 4 partial outputs per cout), one accumulator
+            // register pair at a time; the partials go to this wave's four staged images [oy * 2 + ox][block][cout]
+            int lane_e;  // rebuilt from the hardware lane id: a tile-loop invariant would be hoisted to the kernel entry and spilled
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+            float *wr = stage + wave * (4 * W3_IMG) + (lane_e & 31) * W3_PITCH + 4 * (lane_e >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 P[2][4];  // [oy][xi_x]
+#pragma unroll
+                for (int fx = 0; fx < 4; ++fx) {
+                    const f32x2 a0 = {acc[0 * 4 + fx][r], acc[0 * 4 + fx][r + 1]}, a1 = {acc[1 * 4 + fx][r], acc[1 * 4 + fx][r + 1]};
+                    const f32x2 a2 = {acc[2 * 4 + fx][r], acc[2 * 4 + fx][r + 1]}, a3 = {acc[3 * 4 + fx][r], acc[3 * 4 + fx][r + 1]};
+                    P[0][fx] = pk_add(pk_add(a0, a1), a2);
+                    P[1][fx] = pk_sub(pk_sub(a1, a2), a3);
+                }
+                const int co = (r & 3) + 8 * (r >> 2);  // + 4 * half: in wr
+#pragma unroll
+                for (int oy = 0; oy < 2; ++oy) {
+                    *(f32x2 *)(wr + (oy * 2 + 0) * W3_IMG + co) = pk_add(pk_add(P[oy][0], P[oy][1]), P[oy][2]);
+                    *(f32x2 *)(wr + (oy * 2 + 1) * W3_IMG + co) = pk_sub(pk_sub(P[oy][1], P[oy][2]), P[oy][3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            W3_T(t_e1);
+            W3_ACC(3, t_e0, t_e1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // (raw: a __syncthreads() would also drain the brick DMAs of the next tile)
+            asm volatile("" ::: "memory");  // the intrinsic is IntrNoMem: without this hipcc may issue the read-back ABOVE the barrier
+            // the next tile's first weight fragments (fetched during step 3) are retired BEFORE this tile's stores are issued: loads
+            // and stores of a wave may complete out of order with each other, a count-based wait taken behind the stores could not
+            // tell them apart.  The next tile's first step then starts without any wait.
+            { auto &u0 = uq[0]; W3_UWAIT(u0, 0); }
+
+            // ---- phase 2: wave (oy, ox) adds the four xi_z partials (A^T along z), bias, LeakyReLU, whole-line stores.
+            // Lane = (block row srow + 8 t, 4 couts `piece`): 8 lanes hold the 32 couts = the 128-B line of one voxel.
+            const int oy = wave >> 1, ox = wave & 1;
+            const int srow = lane_e >> 3, piece = lane_e & 7;
+            const float *rd = stage + wave * W3_IMG + srow * W3_PITCH + piece * 4;
+            const int co0 = (int)blockIdx.y * 32;
+            const f32x4 bias = *(const f32x4 *)(p.bias + co0 + piece * 4);
+            const f32x2 b01 = {bias[0], bias[1]}, b23 = {bias[2], bias[3]};
+            float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.act == ACT_LRELU ? p.slope : 1.0f)));
+            asm volatile("" : "+s"(slope));
+            const f32x2 slope2 = {slope, slope};
+            // voxel of block b = 8 t + srow: bx = b & 3, by = (b >> 2) & 3 = 2 (t & 1) + (srow >> 2), bz = b >> 4 = t >> 1
+            const int vx = cur.ox0 + 2 * (srow & 3) + ox;
+            const size_t row_elems = (size_t)p.W * p.Cout;
+            float *obase = p.out + (((size_t)cur.n * p.D + cur.oz0) * p.H + cur.oy0 + oy) * row_elems + co0;  // wave-uniform
+            const unsigned lane_off = (unsigned)(((2 * (srow >> 2)) * p.W + vx) * p.Cout + piece * 4);
+            float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 pz[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pz[k] = *(const f32x4 *)(rd + k * (4 * W3_IMG) + 8 * t * W3_PITCH);
+                // row of blocks (bz = t >> 1, by = 2 (t & 1) + ...): z = oz0 + 2 bz + oz, y = oy0 + 2 by + oy
+                float *rowp = obase + ((size_t)(2 * (t >> 1)) * p.H + 4 * (t & 1)) * row_elems;
+#pragma unroll
+                for (int oz = 0; oz < 2; ++oz) {
+                    f32x2 x0, x1, y0, y1;
+                    if (oz == 0) {
+                        x0 = pk_add(pk_add(f32x2{pz[0][0], pz[0][1]}, f32x2{pz[1][0], pz[1][1]}), f32x2{pz[2][0], pz[2][1]});
+                        x1 = pk_add(pk_add(f32x2{pz[0][2], pz[0][3]}, f32x2{pz[1][2], pz[1][3]}), f32x2{pz[2][2], pz[2][3]});
+                    } else {
+                        x0 = pk_sub(pk_sub(f32x2{pz[1][0], pz[1][1]}, f32x2{pz[2][0], pz[2][1]}), f32x2{pz[3][0], pz[3][1]});
+                        x1 = pk_sub(pk_sub(f32x2{pz[1][2], pz[1][3]}, f32x2{pz[2][2], pz[2][3]}), f32x2{pz[3][2], pz[3][3]});
+                    }
+                    f32x4 val;
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(x0) : "v"(x0), "v"(b01));
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(x1) : "v"(x1), "v"(b23));
+                    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y0) : "v"(x0), "v"(slope2));
+                    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y1) : "v"(x1), "v"(slope2));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(val[0]) : "v"(x0[0]), "v"(y0[0]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(val[1]) : "v"(x0[1]), "v"(y0[1]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(val[2]) : "v"(x1[0]), "v"(y1[0]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(val[3]) : "v"(x1[1]), "v"(y1[1]));
+                    if constexpr (EPI == 2) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { st1[k] += val[k]; st2[k] = fmaf(val[k], val[k], st2[k]); }
+                    }
+                    if constexpr ((MI355_W3_ABL & 32) != 0) asm volatile("" :: "v"(val));
+                    else {
+                        float *gp = rowp + (size_t)oz * p.H * row_elems + lane_off;
+                        // sc1: nothing on this XCD reads the line again (conv3d.hip, FETCH_SIZE -38 % on the 32 -> 32 layer).
+                        // s_nop 2: the VALU instructions of the next output row may be allocated onto these four data registers right
+                        // behind the store; with one wait state (what conv3d.hip's stores carry) dword 1 of the lanes that are read out
+                        // last came out as the NEXT row's intermediate (tools/wino3_probe: couts 17, 21, 25, 29 of every other block)
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" :: "v"(gp), "v"(val) : "memory");
+                    }
+                }
+            }
+            if constexpr (EPI == 2) {
+                // the eight lanes with the same `piece` (lane bits 3..5) hold the same four couts of different voxels
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float a = st1[k], b = st2[k];
+#pragma unroll
+                    for (int m = 8; m < 64; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+                    if (lane_e < 8) {
+                        red[(wave * 32 + 4 * lane_e + k) * 2 + 0] = a;
+                        red[(wave * 32 + 4 * lane_e + k) * 2 + 1] = b;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (wave == 0) {
+                    const int c = lane_e >> 1, k = lane_e & 1;
+                    double tot = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) tot += (double)red[(w * 32 + c) * 2 + k];
+                    atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co0 + c) * 2 + k, quantise_partial(tot, k, (long)p.D * p.H * p.W));  // exact, order-independent (common.h)
+                }
+            }
+        }
+        cur = nxt_tile;
+        W3_T(t_e2);
+        W3_ACC(4, t_e0, t_e2);
+        W3_CNT(7);
+    }
+    W3_T(t_kernel1);
+    W3_ACC(5, t_kernel0, t_kernel1);
+#undef W3_ULOAD
+#undef W3_UWAIT
+}
+
+// 3-D Winograd pack (floats): [cout block of 32][chunk of 16][quad q][xi_z][f / 2][lane][f & 1][j 0..1], f = xi_y * 4 + xi_x, with
+//   cout = block * 32 + (lane & 31), cin = chunk * 16 + q * 4 + (lane >> 5) * 2 + j, U = G w G^T along all three tap axes,
+//   G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]], evaluated in fp64 and rounded once.
+void pack_conv_weights_wino3(const float *w, int cin, int cin_pad, int cout, std::vector<float> &out) {
+    const int nchunks = cin_pad / 16, nblk = cout / 32;
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    out.assign((size_t)nblk * nchunks * 4 * 4 * 2048, 0.f);
+    // U of one (cout, cin): 64 components
+    std::vector<double> U((size_t)cout * cin * 64);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float *wk = &w[((size_t)co * cin + ci) * 27];
+            double t1[4][3][3], t2[4][4][3];
+            for (int fz = 0; fz < 4; ++fz)
+                for (int dy = 0; dy < 3; ++dy)
+                    for (int dx = 0; dx < 3; ++dx) {
+                        double s = 0.0;
+                        for (int dz = 0; dz < 3; ++dz) s += Gm[fz][dz] * (double)wk[dz * 9 + dy * 3 + dx];
+                        t1[fz][dy][dx] = s;
+                    }
+            for (int fz = 0; fz < 4; ++fz)
+                for (int fy = 0; fy < 4; ++fy)
+                    for (int dx = 0; dx < 3; ++dx) {
+                        double s = 0.0;
+                        for (int dy = 0; dy < 3; ++dy) s += Gm[fy][dy] * t1[fz][dy][dx];
+                        t2[fz][fy][dx] = s;
+                    }
+            double *u = &U[((size_t)co * cin + ci) * 64];
+            for (int fz = 0; fz < 4; ++fz)
+                for (int fy = 0; fy < 4; ++fy)
+                    for (int fx = 0; fx < 4; ++fx) {
+                        double s = 0.0;
+                        for (int dx = 0; dx < 3; ++dx) s += Gm[fx][dx] * t2[fz][fy][dx];
+                        u[(fz * 4 + fy) * 4 + fx] = s;
+                    }
+        }
+    size_t o = 0;
+    for (int b = 0; b < nblk; ++b)
+        for (int ch = 0; ch < nchunks; ++ch)
+            for (int q = 0; q < 4; ++q)
+                for (int fz = 0; fz < 4; ++fz)
+                    for (int fp = 0; fp < 8; ++fp)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int fj = 0; fj < 4; ++fj, ++o) {
+                                const int f = fp * 2 + (fj >> 1), j = fj & 1;
+                                const int co = b * 32 + (lane & 31);
+                                const int ci = ch * 16 + q * 4 + (lane >> 5) * 2 + j;
+                                if (ci >= cin) continue;
+                                out[o] = (float)U[((size_t)co * cin + ci) * 64 + fz * 16 + f];
+                            }
+}
+
+static int wino3_mode() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MI355_WINO3"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+bool conv3d_wino3_enabled() { return wino3_mode() != 0; }
+
+// Launches when the call fits the kernel (says so in *taken): stride 1, whole 4 x 8 x 8 tiles, 16-channel chunks on both halves
+// of a virtual concat, enough tiles to fill the chip, no fused head.
+int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name, bool *taken) {
+    *taken = false;
+    if (!wino3_mode() || !w.wp3_dev || w.stride != 1 || c.head_out) return MI355_OK;
+    if (c.Di % 4 || c.Hi % 8 || c.Wi % 8 || c.C0 % 16 || c.C1 % 16 || w.cout % 32 || (c.C0 + c.C1) != w.cin_pad) return MI355_OK;
+    const int tx = c.Wi / 8, ty = c.Hi / 8, tz = c.Di / 4;
+    const long tiles = (long)tx * ty * tz * c.N;
+    if (tiles * (w.cout / 32) < 1024 || tiles >= (1l << 30)) return MI355_OK;
+    if ((long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) >= (1l << 31)) return MI355_OK;  // the per-lane part of a DMA address fits 32 bits
+    Wino3Args a;
+    a.in0 = c.in0; a.in1 = c.in1; a.wp = w.wp3_dev; a.bias = w.bias_dev; a.out = c.out; a.stats = c.stats;
+    a.C0 = c.C0; a.C1 = c.C1; a.N = c.N; a.D = c.Di; a.H = c.Hi; a.W = c.Wi; a.Cout = w.cout;
+    a.nchunks = w.cin_pad / 16; a.act = c.act; a.slope = c.slope;
+    a.total_tiles = (int)tiles;
+    a.div_tiles_per_n = make_fastdiv(tx * ty * tz);
+    a.order = make_tile_order(tx, ty, tz);
+    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_ncls = 0;
+    float *zeros = nullptr;
+    MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
+    a.zeros = zeros;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
+        MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
+        attr_set = true;
+    }
+    const int gy = w.cout / 32;
+    int gx = 256 / gy;                      // one persistent workgroup per CU
+    gx = gx < 8 ? 8 : (gx / 8) * 8;         // multiple of 8: blockIdx.x & 7 labels the XCD group
+    const int need = (int)((tiles + 7) / 8) * 8;
+    if (gx > need) gx = need;
+    if (c.stats) {
+        if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<2>";
+        hipLaunchKernelGGL(conv3_f32_wino3_kernel<2>, dim3(gx, gy), dim3(256), W3_LDS_BYTES, s, a);
+    } else {
+        if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<0>";
+        hipLaunchKernelGGL(conv3_f32_wino3_kernel<0>, dim3(gx, gy), dim3(256), W3_LDS_BYTES, s, a);
+    }
+    MI355_HIP(hipGetLastError());
+    *taken = true;
+    return MI355_OK;
+}
+
+}  // namespace mi355

@@ -19,6 +19,7 @@ struct ConvWeights {
     float *wp16_dev = nullptr;  // second pack with 16-channel chunks for the 512-voxel-tile simple kernel (auto mode)
     float *wpw_dev = nullptr;   // Winograd pack (stride 1, 16-channel chunks, 32-cout blocks): F(2,3) along y, or
     bool wino2 = false;         // F(2x2,3x3) over (z, y) when wino2
+    float *wp3_dev = nullptr;   // 3-D Winograd pack F(2x2x2,3x3x3) (conv3d_wino3.hip; stride 1, 16-channel chunks, 32-cout blocks)
     float *bias_dev = nullptr;
     float *w_plain_dev = nullptr;  // [cout][cin][27] PyTorch order (direct kernel / tests)
     size_t wp_bytes = 0;
@@ -44,6 +45,10 @@ struct ConvCall {
     int head_ncls = 0;
 };
 int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name = nullptr);
+// F(2x2x2, 3x3x3) kernel (conv3d_wino3.hip): launches when the call fits it and says so in *taken
+void pack_conv_weights_wino3(const float *w, int cin, int cin_pad, int cout, std::vector<float> &out);
+bool conv3d_wino3_enabled();
+int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name, bool *taken);
 int conv3d_direct_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s);
 
 // first conv of the network (Cin <= 4): x-taps folded into K, NDHW4 input (conv_stem.hip)

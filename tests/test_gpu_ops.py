@@ -43,7 +43,22 @@ CONV_CASES = [
     (3, 30, 37, 70, 48, 32, 1, 0),     # Winograd kernel: ragged in z, y (odd: half-used row pair) and x, 3 chunks, batch
     (2, 16, 64, 128, 16, 32, 1, 1),    # Winograd kernel: ONE 16-channel chunk per tile, 4 x 16 x 4 tiles per sample -> blocked tile order 4 x 4 x 2
     (1, 24, 64, 256, 32, 32, 1, 1),    # Winograd kernel: 8 x-tiles and 6 z-tiles (not a power of two -> linear tile order), whole-line stores
+    (2, 32, 64, 64, 48, 64, 1, 1),     # F(2x2x2,3x3x3) kernel: whole 4 x 8 x 8 tiles, 3 chunks, two cout blocks, batch
+    (1, 30, 64, 64, 32, 32, 1, 0),     # z not a multiple of 4: stays on the F(2x2,3x3) kernel
+    (1, 64, 64, 72, 16, 32, 1, 1),     # F(2x2x2,3x3x3): one chunk per tile, 9 x-tiles (linear tile order), 1152 tiles on 256 workgroups (uneven)
 ]
+
+#: which kernel an fp32 case is written for (asserted through mi355_last_conv_kernel)
+F32_EXPECT_KERNEL = {
+    (1, 64, 64, 64, 32, 64, 1, 1): "conv3_f32_wino3_kernel<0>",
+    (2, 16, 64, 128, 16, 32, 1, 1): "conv3_f32_wino3_kernel<0>",
+    (1, 24, 64, 256, 32, 32, 1, 1): "conv3_f32_wino3_kernel<0>",
+    (2, 32, 64, 64, 48, 64, 1, 1): "conv3_f32_wino3_kernel<0>",
+    (1, 64, 64, 72, 16, 32, 1, 1): "conv3_f32_wino3_kernel<0>",
+    (3, 30, 37, 70, 48, 32, 1, 0): "conv3_f32_wino2_kernel<0>",
+    (1, 30, 64, 64, 32, 32, 1, 0): "conv3_f32_wino2_kernel<0>",
+    (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f32_s2dma_kernel<5>",
+}
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -55,10 +70,14 @@ def test_conv3d_mfma_matches_torch(amd, gpu, case):
     b = _rand(rs, cout)
     ref = _ref_conv(x, wt, b, stride, act, 0.01)
     y = amd.ops.conv3d_ndhwc(torch.from_numpy(x).to(gpu), wt, b, stride=stride, act=act, slope=0.01, impl="mfma")
+    ran = amd.ops.last_conv_kernel()
     y = y.cpu().numpy()
     assert y.shape == ref.shape
     err = np.abs(y - ref).max()
-    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), f"max abs err {err}"
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), f"max abs err {err} ({ran})"
+    import os
+    if case in F32_EXPECT_KERNEL and not any(k in os.environ for k in ("MI355_CONV_IMPL", "MI355_WINOGRAD", "MI355_WINO3", "MI355_S2_DMA", "MI355_SPLITK")):
+        assert ran == F32_EXPECT_KERNEL[case], ran
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[5], (1, 6, 5, 7, 5, 7, 1, 1)])
@@ -221,7 +240,9 @@ SUMS_CASES = [
     (3, 9, 7, 131, 48, 96, 2, 0, "f16"),     # stride 2, odd dims, ragged
     (2, 8, 12, 40, 4, 32, 1, 0, "f16"),      # first layer (Cin = 4), ragged in y
     (1, 16, 16, 32, 4, 64, 1, 1, "f16"),     # first layer, two cout blocks
-    (8, 32, 32, 32, 32, 32, 1, 0, "f32"),    # F(2x2,3x3) Winograd kernel, statistics instantiation
+    (8, 32, 32, 32, 32, 32, 1, 0, "f32"),    # F(2x2x2,3x3x3) Winograd kernel, statistics instantiation
+    (8, 30, 32, 32, 32, 32, 1, 0, "f32"),    # F(2x2,3x3) Winograd kernel (z not a multiple of 4), statistics instantiation
+    (2, 32, 64, 64, 48, 64, 1, 1, "f32"),    # F(2x2x2,3x3x3), statistics behind an activation, two cout blocks, 3 chunks
     (2, 16, 16, 64, 16, 64, 1, 1, "f32"),    # direct f32 kernels
     (2, 10, 6, 14, 64, 32, 2, 0, "f32"),     # stride 2, ragged
     (2, 64, 64, 128, 32, 64, 2, 0, "f32"),   # persistent stride-2 kernel
@@ -231,7 +252,9 @@ SUMS_EXPECT_KERNEL = {
     (8, 32, 32, 32, 64, 64, 1, 0, "f16"): "conv3_f16_dma_kernel<true, false>",
     (4, 24, 40, 72, 16, 64, 1, 1, "f16"): "conv3_f16_dma_kernel<true, false>",
     (2, 64, 64, 64, 32, 128, 2, 0, "f16"): "conv3_f16_s2dma_kernel<true>",
-    (8, 32, 32, 32, 32, 32, 1, 0, "f32"): "conv3_f32_wino2_kernel<2>",
+    (8, 32, 32, 32, 32, 32, 1, 0, "f32"): "conv3_f32_wino3_kernel<2>",
+    (8, 30, 32, 32, 32, 32, 1, 0, "f32"): "conv3_f32_wino2_kernel<2>",
+    (2, 32, 64, 64, 48, 64, 1, 1, "f32"): "conv3_f32_wino3_kernel<2>",
     (2, 64, 64, 128, 32, 64, 2, 0, "f32"): "conv3_f32_s2dma_kernel<5>",
 }
 
@@ -263,7 +286,7 @@ def test_conv3d_norm_sums_match_reference(amd, gpu, case):
     msq_err = np.abs(sums[..., 1] / V - msq_ref) / msq_ref
     assert mean_err.max() <= 1e-4 and msq_err.max() <= 1e-4, f"mean err {mean_err.max():.2e} rms, mean-square err {msq_err.max():.2e} ({ran})"
     import os
-    if case in SUMS_EXPECT_KERNEL and not any(k in os.environ for k in ("MI355_CONV_IMPL", "MI355_F16_DMA", "MI355_F16_S2", "MI355_S2_DMA", "MI355_WINOGRAD")):
+    if case in SUMS_EXPECT_KERNEL and not any(k in os.environ for k in ("MI355_CONV_IMPL", "MI355_F16_DMA", "MI355_F16_S2", "MI355_S2_DMA", "MI355_WINOGRAD", "MI355_WINO3")):
         assert ran == SUMS_EXPECT_KERNEL[case], ran
 
 
@@ -367,7 +390,7 @@ print("OK", worst)
 """
 
 
-@pytest.mark.parametrize("env", [{"MI355_WINOGRAD": "0"}, {"MI355_WINOGRAD": "1"}, {"MI355_S2_DMA": "0", "MI355_SPLITK": "0"},
+@pytest.mark.parametrize("env", [{"MI355_WINOGRAD": "0"}, {"MI355_WINOGRAD": "1"}, {"MI355_WINO3": "0"}, {"MI355_S2_DMA": "0", "MI355_SPLITK": "0"},
                                  {"MI355_CONV_IMPL": "0"}, {"MI355_F16_DMA": "0"}])
 def test_conv_dispatch_switches_keep_working(amd, gpu, env):
     """The A/B switches select the older kernels behind the same entry points (direct instead of Winograd, simple
