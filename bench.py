@@ -48,10 +48,12 @@ PEAK_HBM_GBS = 8000.0
 PATCH = (128, 128, 128)
 DICE_GATE = 0.999  # BASELINE.json north_star: Dice against the reference CPU output >= 0.999
 # Winograd kernels execute fewer multiplies than the algorithmic (direct-convolution) count that `achieved` uses:
-# F(2,3) along y issues 2/3 of the direct MFMAs, F(2x2,3x3) over (z,y) 4/9; frac can therefore exceed 1 and
+# F(2,3) along y issues 2/3 of the direct MFMAs, F(2x2,3x3) over (z,y) 4/9, F(2x2x2,3x3x3) 8/27; frac can therefore exceed 1 and
 # frac_executed = matrix-pipe utilisation is reported beside it.
 EXECUTED_RATIO = {"conv3_f32_wino_kernel": 2.0 / 3.0, "conv3_f32_wino2_kernel<0>": 4.0 / 9.0, "conv3_f32_wino2_kernel<1>": 4.0 / 9.0,
-                  "conv3_f32_wino2_kernel<2>": 4.0 / 9.0}
+                  "conv3_f32_wino2_kernel<2>": 4.0 / 9.0,
+                  # F(2x2x2,3x3x3): 64 multiplies per 2x2x2 outputs and (cin, cout) instead of 8 * 27
+                  "conv3_f32_wino3_kernel<0>": 8.0 / 27.0, "conv3_f32_wino3_kernel<1>": 8.0 / 27.0, "conv3_f32_wino3_kernel<2>": 8.0 / 27.0}
 
 WORKLOADS = {
     2: dict(models=[("A", 7)], tta=False, dtype="f32",

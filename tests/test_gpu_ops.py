@@ -44,7 +44,7 @@ CONV_CASES = [
     (2, 16, 64, 128, 16, 32, 1, 1),    # Winograd kernel: ONE 16-channel chunk per tile, 4 x 16 x 4 tiles per sample -> blocked tile order 4 x 4 x 2
     (1, 24, 64, 256, 32, 32, 1, 1),    # Winograd kernel: 8 x-tiles and 6 z-tiles (not a power of two -> linear tile order), whole-line stores
     (2, 32, 64, 64, 48, 64, 1, 1),     # F(2x2x2,3x3x3) kernel: whole 4 x 8 x 8 tiles, 3 chunks, two cout blocks, batch
-    (1, 30, 64, 64, 32, 32, 1, 0),     # z not a multiple of 4: stays on the F(2x2,3x3) kernel
+    (2, 30, 64, 128, 32, 32, 1, 0),     # z not a multiple of 4: stays on the F(2x2,3x3) kernel
     (1, 64, 64, 72, 16, 32, 1, 1),     # F(2x2x2,3x3x3): one chunk per tile, 9 x-tiles (linear tile order), 1152 tiles on 256 workgroups (uneven)
 ]
 
@@ -56,7 +56,7 @@ F32_EXPECT_KERNEL = {
     (2, 32, 64, 64, 48, 64, 1, 1): "conv3_f32_wino3_kernel<0>",
     (1, 64, 64, 72, 16, 32, 1, 1): "conv3_f32_wino3_kernel<0>",
     (3, 30, 37, 70, 48, 32, 1, 0): "conv3_f32_wino2_kernel<0>",
-    (1, 30, 64, 64, 32, 32, 1, 0): "conv3_f32_wino2_kernel<0>",
+    (2, 30, 64, 128, 32, 32, 1, 0): "conv3_f32_wino2_kernel<0>",
     (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f32_s2dma_kernel<5>",
 }
 
