@@ -76,11 +76,11 @@ constexpr int W3_BUF = 4 * W3_PS * 4;           // floats per brick buffer (4 qu
 constexpr int W3_PITCH = 36;                    // floats per staged block row (128 B + 16 B)
 constexpr int W3_IMG = 32 * W3_PITCH;           // one staged image: 32 blocks x 32 couts
 constexpr int W3_STAGE = 4 * 4 * W3_IMG;        // [wave = xi_z][oy, ox][block][cout]
-constexpr int W3_JUNK = 64 * 4;                 // destination of the dummy DMAs that keep the per-wave DMA count uniform
-constexpr size_t W3_LDS_BYTES = (size_t)(2 * W3_BUF + W3_STAGE + W3_JUNK + 4 * 32 * 2) * sizeof(float);
+constexpr size_t W3_LDS_BYTES = (size_t)(2 * W3_BUF + W3_STAGE + 4 * 32 * 2) * sizeof(float);
 static_assert(W3_LDS_BYTES <= 160 * 1024, "LDS budget");
 
-// EPI: 0 = bias + LeakyReLU + store, 2 = the same + Instance/GroupNorm statistics (sum x, sum x^2 per sample and cout)
+// EPI: 0 = bias + LeakyReLU + store, 1 = fused 1x1x1 segmentation head (the network's last conv, Cout = 32: only the logits are
+// written), 2 = as 0 + Instance/GroupNorm statistics (sum x, sum x^2 per sample and cout)
 template <int EPI>
 __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     const int half = lane >> 5, l31 = lane & 31;
     const int bx = l31 & 3, by = (l31 >> 2) & 3, bz = l31 >> 4;
     float *stage = lds + 2 * W3_BUF;
-    float *junk = stage + W3_STAGE;
-    float *red = junk + W3_JUNK;
+    float *red = stage + W3_STAGE;
 
     // tile sequence of this workgroup: XCD group x owns one contiguous range of tile ids
     const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
@@ -115,13 +114,14 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         return tc;
     };
 
-    // brick DMA: range r = 64 consecutive slots of every quad plane; wave w issues ranges w, w + 4, w + 8 (the last one only
-    // exists for waves 0 and 1: the others send theirs to a junk area from the zero page, so that every wave has the same
-    // number of vector-memory operations in flight and the hand-counted waits below hold for all four)
+    // brick DMA: range r = 64 consecutive slots of a quad plane, 10 ranges x 4 quads = 40 wave-instructions per chunk, ten per wave
+    // (the hand-counted waits below need the same number of vector-memory operations in flight in all four waves): group 0 = range
+    // w, group 1 = range w + 4 (four quads each, issued back to back: they share their 128-B lines), group 2 = two quads of range
+    // 8 (waves 0, 1) or 9 (waves 2, 3).
     unsigned dma_pk[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int v = (wave + 4 * k) * 64 + lane;
+        const int v = (k < 2 ? wave + 4 * k : 8 + (wave >> 1)) * 64 + lane;
         const int pad = v >= W3_BV ? 1 : 0;
         const int vv = pad ? 0 : v;
         const int rz = vv / 100, rem = vv - rz * 100;
@@ -129,38 +129,39 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         const int par = r2 / 5, xh = r2 - par * 5;
         dma_pk[k] = (unsigned)(rz | (ry << 4) | ((2 * xh + par) << 8) | (pad << 16));
     }
-    auto dma_group = [&](const TileCoord &tc, int ch, int k, float *buf) {
-        const int rng = wave + 4 * k;
-        const bool dummy = rng >= 10;  // scalar
+    auto dma_group = [&](const TileCoord &tc, int ch, auto kc, float *buf) {
+        constexpr int k = decltype(kc)::value;
+        const int rng = k < 2 ? wave + 4 * k : 8 + (wave >> 1);  // scalar
+        const int q0 = k < 2 ? 0 : 2 * (wave & 1);
         const int cglob = ch * 16;
         const float *src; int Csrc, coff;
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
-        src += ((((size_t)tc.n * p.D + (tc.oz0 - 1)) * p.H + (tc.oy0 - 1)) * p.W + (tc.ox0 - 1)) * (long)Csrc + coff;
+        src += ((((size_t)tc.n * p.D + (tc.oz0 - 1)) * p.H + (tc.oy0 - 1)) * p.W + (tc.ox0 - 1)) * (long)Csrc + coff + 4 * q0;
         unsigned pk = dma_pk[k];
         asm volatile("" : "+v"(pk));  // unpack here, every time (hoisted out of the tile loop the fields get spilled)
         const int rz = pk & 15, ry = (pk >> 4) & 15, rx = (pk >> 8) & 15, pad = pk >> 16;
-        const bool in_vol = !pad && !dummy && ((unsigned)(tc.oz0 - 1 + rz) < (unsigned)p.D) && ((unsigned)(tc.oy0 - 1 + ry) < (unsigned)p.H) &&
+        const bool in_vol = !pad && ((unsigned)(tc.oz0 - 1 + rz) < (unsigned)p.D) && ((unsigned)(tc.oy0 - 1 + ry) < (unsigned)p.H) &&
                             ((unsigned)(tc.ox0 - 1 + rx) < (unsigned)p.W);
         const int voff = ((rz * p.H + ry) * p.W + rx) * Csrc;
         const float *g = in_vol ? src + voff : p.zeros;
         asm volatile("" : "+v"(g));  // one DMA per quad for every lane (a branchy select would break the vmcnt count)
-        // the instruction's immediate offset is added to the global AND the LDS address: the LDS base of quad Q is moved back by it
-        float *dst = dummy ? junk : buf + rng * 64 * 4;
-        const int qs = dummy ? -4 : (W3_PS * 4 - 4);
+        float *dst = buf + rng * 64 * 4 + q0 * (W3_PS * 4);
         // Inline asm, not __builtin_amdgcn_global_load_lds: hipcc tracks the builtin's LDS writes and, wherever it cannot prove that a
         // ds_read does not alias one in flight - at every loop back edge - it retires ALL vector memory operations (vmcnt(0)) in front
-        // of the read.  This pipeline keeps a DMA group in flight across the chunk loop's back edge by design (the barrier that
-        // publishes the data is what orders it), and the wait cost 650 cycles per chunk (tools/wino3_probe stamps).  M0 = LDS byte
-        // address of lane 0's slot; one wait state between the write of M0 and its use.
+        // of the read; this pipeline keeps a DMA group in flight across the chunk loop's back edge by design (the barrier that
+        // publishes the data is what orders it).  M0 = LDS byte address of lane 0's slot, one wait state between its write and its
+        // use.  The instruction's immediate offset is added to the global AND the LDS address: quad Q's M0 is moved back by it.
         const unsigned m0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)dst;
 #define W3_DMA(Q)                                                                                                         \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%2"                                \
-                 :: "s"(m0 + (unsigned)((Q) * qs * 4)), "v"(g), "n"((Q) * 16) : "memory", "m0")
+                 :: "s"(m0 + (unsigned)((Q) * (W3_PS * 16 - 16))), "v"(g), "n"((Q) * 16) : "memory", "m0")
         W3_DMA(0);
         W3_DMA(1);
-        W3_DMA(2);
-        W3_DMA(3);
+        if constexpr (k < 2) {
+            W3_DMA(2);
+            W3_DMA(3);
+        }
 #undef W3_DMA
     };
 
@@ -236,8 +237,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         if (d_ch + 1 < p.nchunks) { ++d_ch; return; }
         if (d_tile + nl < hi) { d_tile += nl; d_tc = decode(d_tile); d_ch = 0; }
     };
-#pragma unroll
-    for (int k = 0; k < 3; ++k) dma_group(d_tc, d_ch, k, lds);
+    static_for<0, 3>([&](auto kc) { dma_group(d_tc, d_ch, kc, lds); });
     f32x4 uq[2][8];
     static_for<0, 8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         for (int fy = 0; fy < 4; ++fy) x_op(Y, V[0], fy);
     }
     d_advance();
-    dma_group(d_tc, d_ch, 0, lds + W3_BUF);  // ("step 3 of chunk -1")
+    dma_group(d_tc, d_ch, std::integral_constant<int, 0>{}, lds + W3_BUF);  // ("step 3 of chunk -1")
     {   // (the first tile's first step has no weight wait of its own: retire uq[0] here, behind the DMA group - once per kernel)
         auto &u0 = uq[0];
         W3_UWAIT(u0, 0);
@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                 // step finds its weights retired already (the epilogue waits for them before its stores); step 3 follows the
                 // chunk barrier's vmcnt(0)
                 if constexpr (st == 0) { if (ch != 0) W3_UWAIT(uc, 4); }
-                else if constexpr (st < 3) W3_UWAIT(uc, 4);
+                else if constexpr (st == 1) W3_UWAIT(uc, 4);
+                else if constexpr (st == 2) W3_UWAIT(uc, 2);  // (group 2 is two DMAs)
                 else W3_UWAIT(uc, 0);
                 const float *wn = (st + 1 < STEPS) ? wch + (size_t)(st + 1) * (4 * 2048) : wnx;
                 const float *rb = (st + 1 < STEPS) ? bufc : bufn;   // brick the next quad is read from
@@ -318,9 +319,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                         if constexpr ((MI355_W3_ABL & 8) == 0) W3_ULOAD(un[k], wl, wb, (k & 3) * 1024);      // (same cout block, chunk 0)
                     }
                     if constexpr ((MI355_W3_ABL & 4) == 0 && i == 20) {
-                        if constexpr (st == 0) dma_group(d_tc, d_ch, 1, bufn);
-                        if constexpr (st == 1) { dma_group(d_tc, d_ch, 2, bufn); d_advance(); }
-                        if constexpr (st == 3) dma_group(d_tc, d_ch, 0, const_cast<float *>(bufc));
+                        if constexpr (st == 0) dma_group(d_tc, d_ch, std::integral_constant<int, 1>{}, bufn);
+                        if constexpr (st == 1) { dma_group(d_tc, d_ch, std::integral_constant<int, 2>{}, bufn); d_advance(); }
+                        if constexpr (st == 3) dma_group(d_tc, d_ch, std::integral_constant<int, 0>{}, const_cast<float *>(bufc));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -393,6 +394,19 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
             float *obase = p.out + (((size_t)cur.n * p.D + cur.oz0) * p.H + cur.oy0 + oy) * row_elems + co0;  // wave-uniform
             const unsigned lane_off = (unsigned)(((2 * (srow >> 2)) * p.W + vx) * p.Cout + piece * 4);
             float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+            // EPI == 1: logit[c] = sum_cout w[c][cout] * act(y[cout] + b[cout]) + hb[c] (generic_UNet.py:389-391, 1x1x1, no bias in the
+            // reference's head).  A lane holds four couts of its voxel and the other 28 sit in the seven lanes beside it: four fmas per
+            // class, then three DPP additions across the 8-lane group; lane `piece` = c stores class c.
+            constexpr int KMAX = 4;
+            f32x4 hq[KMAX];
+            float hb = 0.f;
+            const int64_t Vo = (int64_t)p.D * p.H * p.W;
+            if constexpr (EPI == 1) {
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c)
+                    hq[c] = c < p.head_ncls ? *(const f32x4 *)(p.head_w + c * p.Cout + co0 + piece * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                hb = piece < p.head_ncls ? p.head_b[piece] : 0.f;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 f32x4 pz[4];
@@ -423,7 +437,22 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { st1[k] += val[k]; st2[k] = fmaf(val[k], val[k], st2[k]); }
                     }
-                    if constexpr ((MI355_W3_ABL & 32) != 0) asm volatile("" :: "v"(val));
+                    if constexpr (EPI == 1) {
+                        float tot[KMAX];
+#pragma unroll
+                        for (int c = 0; c < KMAX; ++c) {
+                            float v = val[0] * hq[c][0];
+                            v = fmaf(val[1], hq[c][1], v); v = fmaf(val[2], hq[c][2], v); v = fmaf(val[3], hq[c][3], v);
+                            v += dpp_perm<0xB1>(v);   // lane ^ 1
+                            v += dpp_perm<0x4E>(v);   // lane ^ 2
+                            v += dpp_perm<0x141>(v);  // row_half_mirror: the other quad of the 8-lane group
+                            tot[c] = v;
+                        }
+                        const float mine = piece == 0 ? tot[0] : piece == 1 ? tot[1] : piece == 2 ? tot[2] : tot[3];
+                        const int vz = cur.oz0 + 2 * (t >> 1) + oz, vy = cur.oy0 + oy + 4 * (t & 1) + 2 * (srow >> 2);
+                        if (piece < p.head_ncls)
+                            p.head_out[((int64_t)cur.n * p.head_ncls + piece) * Vo + ((int64_t)vz * p.H + vy) * p.W + vx] = mine + hb;
+                    } else if constexpr ((MI355_W3_ABL & 32) != 0) asm volatile("" :: "v"(val));
                     else {
                         float *gp = rowp + (size_t)oz * p.H * row_elems + lane_off;
                         // sc1: nothing on this XCD reads the line again (conv3d.hip, FETCH_SIZE -38 % on the 32 -> 32 layer).
@@ -529,10 +558,11 @@ static int wino3_mode() {
 bool conv3d_wino3_enabled() { return wino3_mode() != 0; }
 
 // Launches when the call fits the kernel (says so in *taken): stride 1, whole 4 x 8 x 8 tiles, 16-channel chunks on both halves
-// of a virtual concat, enough tiles to fill the chip, no fused head.
+// of a virtual concat, enough tiles to fill the chip; the fused head needs Cout = 32.
 int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name, bool *taken) {
     *taken = false;
-    if (!wino3_mode() || !w.wp3_dev || w.stride != 1 || c.head_out) return MI355_OK;
+    if (!wino3_mode() || !w.wp3_dev || w.stride != 1) return MI355_OK;
+    if (c.head_out && (w.cout != 32 || c.stats || c.head_ncls < 1 || c.head_ncls > 4 || !c.head_w || !c.head_b)) return MI355_OK;
     if (c.Di % 4 || c.Hi % 8 || c.Wi % 8 || c.C0 % 16 || c.C1 % 16 || w.cout % 32 || (c.C0 + c.C1) != w.cin_pad) return MI355_OK;
     const int tx = c.Wi / 8, ty = c.Hi / 8, tz = c.Di / 4;
     const long tiles = (long)tx * ty * tz * c.N;
@@ -545,13 +575,14 @@ int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, con
     a.total_tiles = (int)tiles;
     a.div_tiles_per_n = make_fastdiv(tx * ty * tz);
     a.order = make_tile_order(tx, ty, tz);
-    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_ncls = 0;
+    a.head_w = c.head_w; a.head_b = c.head_b; a.head_out = c.head_out; a.head_ncls = c.head_ncls;
     float *zeros = nullptr;
     MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
     a.zeros = zeros;
     static bool attr_set = false;
     if (!attr_set) {
         MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
+        MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
         MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
         attr_set = true;
     }
@@ -560,7 +591,10 @@ int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, con
     gx = gx < 8 ? 8 : (gx / 8) * 8;         // multiple of 8: blockIdx.x & 7 labels the XCD group
     const int need = (int)((tiles + 7) / 8) * 8;
     if (gx > need) gx = need;
-    if (c.stats) {
+    if (c.head_out) {
+        if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<1>";
+        hipLaunchKernelGGL(conv3_f32_wino3_kernel<1>, dim3(gx, gy), dim3(256), W3_LDS_BYTES, s, a);
+    } else if (c.stats) {
         if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<2>";
         hipLaunchKernelGGL(conv3_f32_wino3_kernel<2>, dim3(gx, gy), dim3(256), W3_LDS_BYTES, s, a);
     } else {
