@@ -113,12 +113,12 @@ def test_forward_128_model_a(amd, gpu):
     kernels = {e["name"] for e in net.read_profile()}
     net.profile(False)
     _check_logits(got, ref)
-    # the large stride-1 layers of this forward run on the Winograd kernels - F(2x2x2,3x3x3) where the launch is whole 4 x 8 x 8
-    # tiles and large enough (levels 0 and 1 here), F(2x2,3x3) with the fused head for the last conv: the tolerance above is
-    # therefore the Winograd paths' tolerance, not only the direct kernels'
+    # the large stride-1 layers of this forward run on the Winograd kernel F(2x2x2,3x3x3) (whole 4 x 8 x 8 tiles and enough of them:
+    # levels 0 and 1 here), the last conv on its fused-head instantiation: the tolerance above is therefore the Winograd path's
+    # tolerance, not only the direct kernels'
     import os
     if os.environ.get("MI355_WINOGRAD", "2") not in ("0", "1") and os.environ.get("MI355_CONV_IMPL") is None and os.environ.get("MI355_WINO3", "1") != "0":
-        assert "conv3_f32_wino3_kernel<0>" in kernels and "conv3_f32_wino2_kernel<1>" in kernels, sorted(kernels)
+        assert "conv3_f32_wino3_kernel<0>" in kernels and "conv3_f32_wino3_kernel<1>" in kernels, sorted(kernels)
 
 
 def _small_net(amd, norm="batch", seed=21):
