@@ -22,6 +22,9 @@
 //     voxel and lane ^ 32 the other 4: v_permlane32_swap pairs them up and a store instruction writes 2 cout blocks x 4 x-rows
 //     x 8 voxels: whole 128-B lines of the channel-blocked output (common.h) without a transposition through LDS;
 //     sum x and sum x^2 per cout for Instance/GroupNorm as in the other kernels (quantised partials, common.h).
+// CW = couts per workgroup: 128 as above, or 64 (round 4: layers with Cout % 128 != 0, e.g. the 32 -> 64 conv of the base model's
+// level 1, which used to fall back to the register-staged kernel at 0.17 of the peak): the waves then split 2 x 2 - wave & 1
+// picks the 32-cout fragment, wave >> 1 the output z planes {0, 1} or {2, 3} (MF = 2) - over the SAME brick.
 // The stride-2 convs read one input tensor (no virtual concat) and never carry the fused head.
 #include "kernels.h"
 
@@ -74,16 +77,19 @@ struct S2GeomH {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <bool STATS>
+template <bool STATS, int CW = 128>
 __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     typedef S2GeomH G;
-    constexpr int MF = 4;
+    static_assert(CW == 128 || CW == 64, "couts per workgroup");
+    constexpr int MF = CW == 128 ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *bias_lds = (float *)(lds_raw + G::BIAS_OFF);
-    const int co_blk = (int)blockIdx.y * 128;
-    if (tid < 128) bias_lds[tid] = p.bias[co_blk + tid];  // (published by the prologue's barrier)
+    const int co_blk = (int)blockIdx.y * CW;
+    if (tid < CW) bias_lds[tid] = p.bias[co_blk + tid];  // (published by the prologue's barrier)
+    const int wco = CW == 128 ? wave : (wave & 1);          // this wave's 32-cout fragment of the workgroup's couts
+    const int wz = CW == 128 ? 0 : 2 * (wave >> 1);         // first output z plane of this wave's fragments
 
     // this workgroup's tile sequence: XCD group x owns the contiguous range [lo, hi); its workgroups stride through it
     const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
@@ -147,9 +153,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
 
     // LDS byte offset of this lane's voxel fragment 0 in a brick buffer, tap (0, 0, 0): output voxel (y = l31 >> 3, x = l31 & 7)
     // of plane z = mf reads input (2 z + dz, 2 y + dy, 2 x + dx) = row (2 z + dz) * 9 + 2 y + dy, slot x + (dx & 1) * 9 + (dx >> 1)
-    const int a_lane = half * G::PLANE_BYTES + ((2 * (l31 >> 3)) * G::ROW + (l31 & 7)) * 16;
-    // weights: cout block of 64 = 2 blockIdx.y + (wave >> 1), fragment nf = wave & 1 of the nf = 2 pack
-    const char *wblk = (const char *)(p.wp + (size_t)(2 * blockIdx.y + (wave >> 1)) * p.nchunks * (27 * 2 * 512)) + (wave & 1) * 1024;
+    const int a_lane = half * G::PLANE_BYTES + ((2 * (l31 >> 3)) * G::ROW + (l31 & 7)) * 16 + wz * G::MF_STRIDE;
+    // weights: cout block of 64 = 2 blockIdx.y + (wave >> 1) (CW = 128) or blockIdx.y (CW = 64), fragment nf = wave & 1 of the nf = 2 pack
+    const char *wblk = (const char *)(p.wp + (size_t)(CW == 128 ? 2 * blockIdx.y + (wave >> 1) : blockIdx.y) * p.nchunks * (27 * 2 * 512)) + (wave & 1) * 1024;
     const unsigned wlane = lane * 16;
 #define S2_WLOAD(DST, SBASE) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(DST) : "v"(wl), "s"(SBASE) : "memory")
 #define S2_WWAIT(W, N) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(W) : "n"(N) : "memory")
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
         f32x16 acc[MF];
         {   // the accumulators start from the bias: cout (r & 3) + 8 (r >> 2) + 4 half of this wave's 32
             typedef const __attribute__((address_space(3))) f32x4 lds_cf32x4;
-            unsigned bl = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)bias_lds + (wave * 32 + half * 4) * 4;
+            unsigned bl = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)bias_lds + (wco * 32 + half * 4) * 4;
             asm volatile("" : "+v"(bl));
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
             int ln = lane;
             asm volatile("" : "+v"(ln));
             const unsigned lane_off = (unsigned)(ln >> 5) * (unsigned)(Vo * 16) + (unsigned)((((ln & 31) >> 3) * p.Wo + (ln & 7)) * 16);  // (< 2^32: host check)
-            const half_t *obase = p.out + (((size_t)cur.n * (p.Cout >> 3) + ((co_blk + wave * 32) >> 3)) * Vo + ((size_t)cur.oz0 * p.Ho + cur.oy0) * p.Wo + cur.ox0) * 8;
+            const half_t *obase = p.out + (((size_t)cur.n * (p.Cout >> 3) + ((co_blk + wco * 32) >> 3)) * Vo + ((size_t)(cur.oz0 + wz) * p.Ho + cur.oy0) * p.Wo + cur.ox0) * 8;
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
                 const float tot = half32_reduce_scatter(s1, s2, lane);
                 const int r = stat_slot_r(lane), k = (lane >> 4) & 1;
                 const int c = 8 * (r >> 2) + 4 * half + (r & 3);
-                atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co_blk + wave * 32 + c) * 2 + k, quantise_partial((double)tot, k, (long)p.Do * p.Ho * p.Wo));
+                atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co_blk + wco * 32 + c) * 2 + k, quantise_partial((double)tot, k, (long)p.Do * p.Ho * p.Wo));
             }
         }
         cur = nxt_tile;
@@ -321,13 +327,14 @@ int conv3d_f16_s2dma(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, c
     *taken = false;
     static int on = -1;
     if (on < 0) { const char *e = getenv("MI355_F16_S2"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on || w.stride != 2 || w.nf != 2 || w.cout % 128 != 0 || c.head_out || c.C1 != 0 || c.in_scale || c.C0 != w.cin_pad || c.C0 % 16 != 0) return MI355_OK;
+    if (!on || w.stride != 2 || w.nf != 2 || w.cout % 64 != 0 || c.head_out || c.C1 != 0 || c.in_scale || c.C0 != w.cin_pad || c.C0 % 16 != 0) return MI355_OK;
     if ((c.Di | c.Hi | c.Wi) & 1) return MI355_OK;
     const int Do = c.Di / 2, Ho = c.Hi / 2, Wo = c.Wi / 2;
     if (Do % G::TZ || Ho % G::TY || Wo % G::TX) return MI355_OK;
     const int tiles_x = Wo / G::TX, tiles_y = Ho / G::TY, tiles_z = Do / G::TZ;
     const long tiles = (long)tiles_x * tiles_y * tiles_z * c.N;
-    const int gy = w.cout / 128;
+    const int cw = w.cout % 128 == 0 ? 128 : 64;
+    const int gy = w.cout / cw;
     if (tiles * gy < 256 || tiles >= (1l << 30)) return MI355_OK;
     if ((long)G::IZ * c.Hi * c.Wi >= (1l << 24) || (long)G::IZ * c.Hi * c.Wi * 16 >= (1l << 32) || (long)Do * Ho * Wo * 64 >= (1l << 32)) return MI355_OK;
     S2ArgsH a;
@@ -344,7 +351,7 @@ int conv3d_f16_s2dma(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, c
     gx = gx < 8 ? 8 : (gx / 8) * 8;
     const int need = (int)((tiles + 7) / 8) * 8;
     if (gx > need) gx = need;
-    static bool attr_set[2] = {false, false};
+    static bool attr_set[4] = {false, false, false, false};
     auto launch = [&](auto kern, int idx) -> int {
         if (!attr_set[idx]) {
             MI355_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
@@ -355,9 +362,14 @@ int conv3d_f16_s2dma(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, c
         return MI355_OK;
     };
     *taken = true;
+    if (cw == 64) {
+        if (kernel_name) *kernel_name = c.stats ? "conv3_f16_s2dma_kernel<true, 64>" : "conv3_f16_s2dma_kernel<false, 64>";
+        if (c.stats) return launch(conv3_f16_s2dma_kernel<true, 64>, 2);
+        return launch(conv3_f16_s2dma_kernel<false, 64>, 3);
+    }
     if (kernel_name) *kernel_name = c.stats ? "conv3_f16_s2dma_kernel<true>" : "conv3_f16_s2dma_kernel<false>";
-    if (c.stats) return launch(conv3_f16_s2dma_kernel<true>, 0);
-    return launch(conv3_f16_s2dma_kernel<false>, 1);
+    if (c.stats) return launch(conv3_f16_s2dma_kernel<true, 128>, 0);
+    return launch(conv3_f16_s2dma_kernel<false, 128>, 1);
 }
 
 }  // namespace mi355

@@ -234,8 +234,15 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     TileCoord d_tc = cur;
     int d_tile = tile, d_ch = 0;
     auto d_advance = [&]() {
-        if (d_ch + 1 < p.nchunks) { ++d_ch; return; }
-        if (d_tile + nl < hi) { d_tile += nl; d_tc = decode(d_tile); d_ch = 0; }
+        // branch-free (this runs between two MFMAs: a branch would cut the stream into basic blocks): all scalar selects
+        const bool more_ch = d_ch + 1 < p.nchunks;
+        const bool more_tiles = d_tile + nl < hi;
+        const int t2 = more_tiles ? d_tile + nl : d_tile;
+        const TileCoord c2 = decode(t2);
+        const bool wrap = !more_ch && more_tiles;
+        d_ch = more_ch ? d_ch + 1 : (more_tiles ? 0 : d_ch);
+        d_tile = wrap ? t2 : d_tile;
+        d_tc.n = wrap ? c2.n : d_tc.n; d_tc.oz0 = wrap ? c2.oz0 : d_tc.oz0; d_tc.oy0 = wrap ? c2.oy0 : d_tc.oy0; d_tc.ox0 = wrap ? c2.ox0 : d_tc.ox0;
     };
     static_for<0, 3>([&](auto kc) { dma_group(d_tc, d_ch, kc, lds); });
     f32x4 uq[2][8];

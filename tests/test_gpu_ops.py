@@ -181,7 +181,7 @@ F16_CONV_CASES = [
     (1, 16, 16, 32, 4, 64, 1, 0),
     (3, 9, 7, 131, 48, 96, 2, 1),    # stride 2: odd input dims, ragged x tiles, 3 chunks of 16, 3 cout blocks
     (1, 64, 64, 64, 32, 64, 2, 1),   # stride 2 at a network-like size
-    (2, 64, 64, 128, 32, 64, 2, 1),  # stride 2, >= 768 tiles: the pipelined kernel's STRIDE = 2 instantiation
+    (2, 64, 64, 128, 32, 64, 2, 1),  # stride 2, Cout = 64: the LDS-DMA stride-2 kernel with 64 couts per workgroup (round 4)
     (3, 50, 62, 90, 16, 128, 2, 0),  # the same kernel: ragged in z, y, x (odd input dims), two cout blocks, batch
     (8, 32, 30, 32, 128, 256, 2, 1), # the same kernel on a narrow volume (Wo = 16): 2 x 4 x 16 tiles, 8 chunks
     (8, 8, 8, 8, 320, 320, 1, 1),    # deep level: split-K over the 20 channel chunks + finishing pass
@@ -203,7 +203,7 @@ F16_EXPECT_KERNEL = {
     (2, 64, 64, 64, 32, 128, 2, 1): "conv3_f16_s2dma_kernel<false>",
     (2, 32, 32, 64, 64, 256, 2, 0): "conv3_f16_s2dma_kernel<false>",
     (6, 24, 40, 48, 16, 128, 2, 1): "conv3_f16_s2dma_kernel<false>",
-    (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f16_mfma_pipe_kernel<1, 2, false, false, 2, false>",
+    (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f16_s2dma_kernel<false, 64>",
     (8, 8, 8, 8, 320, 320, 1, 1): "conv3_f16_mfma_kernel<1, 2, 2> split-K",
 }
 
@@ -235,6 +235,7 @@ SUMS_CASES = [
     (8, 32, 32, 32, 64, 64, 1, 0, "f16"),    # LDS-DMA kernel, statistics, no activation (conv -> norm -> LeakyReLU)
     (4, 24, 40, 72, 16, 64, 1, 1, "f16"),    # the same kernel with an activation in front of the statistics (ConvDropoutNonlinNorm)
     (2, 64, 64, 64, 32, 128, 2, 0, "f16"),   # stride-2 LDS-DMA kernel
+    (2, 64, 64, 64, 32, 64, 2, 0, "f16"),    # the same kernel with 64 couts per workgroup (waves split 2 x 2: couts x z planes)
     (8, 16, 16, 32, 32, 32, 1, 0, "f16"),    # register-staged kernel, 512-voxel tiles, Cout = 32
     (2, 8, 12, 40, 16, 64, 1, 1, "f16"),     # the same family, ragged tiles: voxels beyond the edge must not count
     (3, 9, 7, 131, 48, 96, 2, 0, "f16"),     # stride 2, odd dims, ragged
@@ -252,6 +253,7 @@ SUMS_EXPECT_KERNEL = {
     (8, 32, 32, 32, 64, 64, 1, 0, "f16"): "conv3_f16_dma_kernel<true, false>",
     (4, 24, 40, 72, 16, 64, 1, 1, "f16"): "conv3_f16_dma_kernel<true, false>",
     (2, 64, 64, 64, 32, 128, 2, 0, "f16"): "conv3_f16_s2dma_kernel<true>",
+    (2, 64, 64, 64, 32, 64, 2, 0, "f16"): "conv3_f16_s2dma_kernel<true, 64>",
     (8, 32, 32, 32, 32, 32, 1, 0, "f32"): "conv3_f32_wino3_kernel<2>",
     (8, 30, 32, 32, 32, 32, 1, 0, "f32"): "conv3_f32_wino2_kernel<2>",
     (2, 32, 64, 64, 48, 64, 1, 1, "f32"): "conv3_f32_wino3_kernel<2>",
