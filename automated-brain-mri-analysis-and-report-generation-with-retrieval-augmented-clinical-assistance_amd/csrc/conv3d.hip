@@ -1735,6 +1735,7 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
         MI355_TRY(conv3d_wino3_f32(w, c, s, kernel_name, &taken));
         if (taken) return MI355_OK;
     }
+    MI355_REQUIRE(!c.in_scale, "conv %d->%d: a pending input normalisation reached a kernel that cannot apply it", w.cin, w.cout);
     if (w.wpw_dev) {
         // auto mode, large launches: Winograd F(2,3) along y on fixed 4x4x32 tiles, 32 couts per workgroup
         ConvArgs b = a;

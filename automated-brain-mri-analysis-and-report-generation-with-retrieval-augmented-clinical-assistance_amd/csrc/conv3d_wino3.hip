@@ -51,6 +51,9 @@ struct Wino3Args {
     const float *head_w, *head_b;
     float *head_out;
     int head_ncls;
+    // INAFF: in0 is the RAW output of the previous block; act(x * in_scale[n][c] + in_shift[n][c]) is applied to the brick in LDS
+    const float *in_scale, *in_shift;
+    float in_slope;  // LeakyReLU slope of that activation, 1 = none
 };
 
 #ifdef MI355_W3_STAMPS
@@ -76,12 +79,19 @@ constexpr int W3_BUF = 4 * W3_PS * 4;           // floats per brick buffer (4 qu
 constexpr int W3_PITCH = 36;                    // floats per staged block row (128 B + 16 B)
 constexpr int W3_IMG = 32 * W3_PITCH;           // one staged image: 32 blocks x 32 couts
 constexpr int W3_STAGE = 4 * 4 * W3_IMG;        // [wave = xi_z][oy, ox][block][cout]
-constexpr size_t W3_LDS_BYTES = (size_t)(2 * W3_BUF + W3_STAGE + 4 * 32 * 2) * sizeof(float);
+constexpr int W3_JUNK = 64 * 4;                 // INAFF: where the in-place writes of out-of-volume pieces go (padding follows the norm)
+constexpr size_t W3_LDS_BYTES = (size_t)(2 * W3_BUF + W3_STAGE + 4 * 32 * 2 + W3_JUNK) * sizeof(float);
 static_assert(W3_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // EPI: 0 = bias + LeakyReLU + store, 1 = fused 1x1x1 segmentation head (the network's last conv, Cout = 32: only the logits are
 // written), 2 = as 0 + Instance/GroupNorm statistics (sum x, sum x^2 per sample and cout)
-template <int EPI>
+// INAFF (round 4): the producer's Instance/GroupNorm (+ LeakyReLU) is applied by THIS conv (generic_UNet.py:62-72 is one expression,
+// lrelu(instnorm(conv(x)))): every lane normalises, in place in LDS, the ten 16-byte pieces it fetched itself - no other lane has
+// seen them before the chunk barrier publishes the brick -, dealt over the MFMA gaps of the step in front of that barrier:
+// ds_read_b128, two v_pk_fma_f32 (scale / shift of the piece's channel quad: wave-uniform, scalar loads), two v_pk_mul_f32 and four
+// v_max_f32 (LeakyReLU as max(y, slope y)), ds_write_b128.  Pieces from outside the volume came from the zero page and must stay
+// zero (padding follows the norm): their write goes to a junk slot.  fp32 arithmetic: bit-compatible with norm_apply_kernel<f32>.
+template <int EPI, bool INAFF = false>
 __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -93,6 +103,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     const int bx = l31 & 3, by = (l31 >> 2) & 3, bz = l31 >> 4;
     float *stage = lds + 2 * W3_BUF;
     float *red = stage + W3_STAGE;
+    float *junk = red + 4 * 32 * 2;
+    unsigned inmask = 0;  // INAFF: bit k = "group k of the chunk being staged lies inside the volume (for this lane)"
 
     // tile sequence of this workgroup: XCD group x owns one contiguous range of tile ids
     const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
@@ -144,6 +156,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         const bool in_vol = !pad && ((unsigned)(tc.oz0 - 1 + rz) < (unsigned)p.D) && ((unsigned)(tc.oy0 - 1 + ry) < (unsigned)p.H) &&
                             ((unsigned)(tc.ox0 - 1 + rx) < (unsigned)p.W);
         const int voff = ((rz * p.H + ry) * p.W + rx) * Csrc;
+        if constexpr (INAFF) inmask = in_vol ? (inmask | (1u << k)) : (inmask & ~(1u << k));
         const float *g = in_vol ? src + voff : p.zeros;
         asm volatile("" : "+v"(g));  // one DMA per quad for every lane (a branchy select would break the vmcnt count)
         float *dst = buf + rng * 64 * 4 + q0 * (W3_PS * 4);
@@ -221,6 +234,61 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         V[fy * 4 + 3] = pk_sub(Y[fy * 4 + 1], Y[fy * 4 + 3]);
     };
 
+    // INAFF: the five piece PAIRS a lane fetched of a chunk - groups 0 and 1: quads (0, 1) and (2, 3) of its range, group 2: its two
+    // quads of range 8 / 9 - are normalised in three phases each (read, compute, write), dealt over MFMA gaps by the caller.
+    struct AffPair { f32x4 r0, r1, s0, s1, t0, t1; };
+    auto aff_slot = [&](float *b, auto gc, auto jc) -> float * {
+        constexpr int g = decltype(gc)::value, j = decltype(jc)::value;
+        const int rng = g < 2 ? wave + 4 * g : 8 + (wave >> 1);
+        const int qa = g < 2 ? 2 * j : 2 * (wave & 1);
+        return b + (qa * W3_PS + rng * 64) * 4 + lane * 4;
+    };
+    auto aff_read = [&](float *b, int n, int ch, auto gc, auto jc, AffPair &a) {
+        constexpr int g = decltype(gc)::value, j = decltype(jc)::value;
+        const int qa = g < 2 ? 2 * j : 2 * (wave & 1);
+        const float *s0 = aff_slot(b, gc, jc);
+        a.r0 = *(const f32x4 *)s0;
+        a.r1 = *(const f32x4 *)(s0 + W3_PS * 4);
+        // scale / shift of the two quads: wave-uniform addresses, read through the CONSTANT address space so that they are scalar
+        // loads (s_load_dwordx4 -> SGPRs, lgkmcnt).  As plain global loads hipcc made vector loads of them - the asm statements
+        // around clobber "memory", so it may not assume the table unchanged - and retired ALL vector memory operations
+        // (vmcnt(0): weights, brick DMAs) in front of every use: +17 % on these launches, more than the separate pass costs.
+        // (The table is written by norm_finalize, a previous launch: reading it through the scalar cache is safe.)
+        const size_t ci = (size_t)n * p.C0 + ch * 16 + 4 * qa;
+        typedef const __attribute__((address_space(4))) f32x4 cf32x4;
+        auto uni = [](const float *q) {
+            const unsigned long long v = (unsigned long long)q;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return (cf32x4 *)(((unsigned long long)hi << 32) | lo);
+        };
+        cf32x4 *sp = uni(p.in_scale + ci), *tp = uni(p.in_shift + ci);
+        a.s0 = sp[0]; a.s1 = sp[1];
+        a.t0 = tp[0]; a.t1 = tp[1];
+    };
+    auto aff_apply = [&](f32x4 &r, const f32x4 &sc, const f32x4 &sh) {
+        const f32x2 sl2 = {p.in_slope, p.in_slope};
+        f32x2 a = {r[0], r[1]}, b = {r[2], r[3]}, ya, yb, za, zb;
+        const f32x2 s01 = {sc[0], sc[1]}, s23 = {sc[2], sc[3]}, t01 = {sh[0], sh[1]}, t23 = {sh[2], sh[3]};
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(ya) : "v"(a), "s"(s01), "v"(t01));  // (one scalar source per instruction: the scale)
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(yb) : "v"(b), "s"(s23), "v"(t23));
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(za) : "v"(ya), "v"(sl2));
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zb) : "v"(yb), "v"(sl2));
+        asm("v_max_f32 %0, %1, %2" : "=v"(r[0]) : "v"(ya[0]), "v"(za[0]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(r[1]) : "v"(ya[1]), "v"(za[1]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(r[2]) : "v"(yb[0]), "v"(zb[0]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(r[3]) : "v"(yb[1]), "v"(zb[1]));
+    };
+    auto aff_compute = [&](AffPair &a) { aff_apply(a.r0, a.s0, a.t0); aff_apply(a.r1, a.s1, a.t1); };
+    auto aff_write = [&](float *b, auto gc, auto jc, const AffPair &a) {
+        constexpr int g = decltype(gc)::value;
+        const bool in = (inmask >> g) & 1;
+        float *s0 = aff_slot(b, gc, jc), *jk = junk + lane * 4;
+        float *d0 = in ? s0 : jk, *d1 = in ? s0 + W3_PS * 4 : jk;
+        *(f32x4 *)d0 = a.r0;
+        *(f32x4 *)d1 = a.r1;
+    };
+    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
+
     // Pipeline (one barrier per chunk, nothing exposed but the very first transform of the kernel):
     //   chunk c, steps 0 1 2: MFMAs of quads 0 1 2; between them the transform of the next quad (from brick buffer c), the next
     //                         step's weights and - steps 0 and 1 - DMA groups 1 and 2 of chunk c + 1 into the other buffer;
@@ -252,6 +320,15 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         W3_ULOAD(u0[k], wl, wb, (k & 3) * 1024);
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int t_n = d_tc.n, t_ch = d_ch;  // INAFF: (sample, chunk) of the brick being staged - the DMA stream moves on before the brick is normalised
+    if constexpr (INAFF) {  // the kernel's first brick: normalised here, exposed once
+        AffPair a;
+        aff_read(lds, t_n, t_ch, I0{}, I0{}, a); aff_compute(a); aff_write(lds, I0{}, I0{}, a);
+        aff_read(lds, t_n, t_ch, I0{}, I1{}, a); aff_compute(a); aff_write(lds, I0{}, I1{}, a);
+        aff_read(lds, t_n, t_ch, I1{}, I0{}, a); aff_compute(a); aff_write(lds, I1{}, I0{}, a);
+        aff_read(lds, t_n, t_ch, I1{}, I1{}, a); aff_compute(a); aff_write(lds, I1{}, I1{}, a);
+        aff_read(lds, t_n, t_ch, I2{}, I0{}, a); aff_compute(a); aff_write(lds, I2{}, I0{}, a);
+    }
     __syncthreads();
     f32x2 dA[8], dB[8], T[16], Y[16], V[2][16];
     {   // the first transform of the kernel (exposed once)
@@ -290,6 +367,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
             const float *wch = wblk + (size_t)ch * (STEPS * 4 * 2048);
             const float *wnx = wblk + (size_t)(last_ch ? 0 : ch + 1) * (STEPS * 4 * 2048);
             W3_T(t_c1);
+            AffPair aff;
             static_for<0, STEPS>([&](auto st_c) {
                 constexpr int st = decltype(st_c)::value;
                 constexpr int pp = st & 1;
@@ -325,9 +403,29 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                         auto &un = uq[pp ^ 1]; const unsigned wl = k < 4 ? wl0 : wl1; const float *wb = wn;  // tile's first fragments
                         if constexpr ((MI355_W3_ABL & 8) == 0) W3_ULOAD(un[k], wl, wb, (k & 3) * 1024);      // (same cout block, chunk 0)
                     }
+                    if constexpr (INAFF && st == 2) {
+                        // the brick of chunk c + 1 (in the other buffer) is normalised here, in front of the barrier that publishes it.
+                        // Groups 0 and 1 have landed (this step's weight wait left only group 2's two DMAs in flight); group 2 is
+                        // retired by vmcnt(8) at i = 27: only this step's eight weight loads are younger.
+                        if constexpr (i == 1) aff_read(bufn, t_n, t_ch, I0{}, I0{}, aff);
+                        if constexpr (i == 3) aff_compute(aff);
+                        if constexpr (i == 4) aff_write(bufn, I0{}, I0{}, aff);
+                        if constexpr (i == 8) aff_read(bufn, t_n, t_ch, I0{}, I1{}, aff);
+                        if constexpr (i == 10) aff_compute(aff);
+                        if constexpr (i == 11) aff_write(bufn, I0{}, I1{}, aff);
+                        if constexpr (i == 16) aff_read(bufn, t_n, t_ch, I1{}, I0{}, aff);
+                        if constexpr (i == 19) aff_compute(aff);
+                        if constexpr (i == 20) aff_write(bufn, I1{}, I0{}, aff);
+                        if constexpr (i == 21) aff_read(bufn, t_n, t_ch, I1{}, I1{}, aff);
+                        if constexpr (i == 23) aff_compute(aff);
+                        if constexpr (i == 24) aff_write(bufn, I1{}, I1{}, aff);
+                        if constexpr (i == 26) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); aff_read(bufn, t_n, t_ch, I2{}, I0{}, aff); }
+                        if constexpr (i == 28) aff_compute(aff);
+                        if constexpr (i == 29) aff_write(bufn, I2{}, I0{}, aff);
+                    }
                     if constexpr ((MI355_W3_ABL & 4) == 0 && i == 20) {
                         if constexpr (st == 0) dma_group(d_tc, d_ch, std::integral_constant<int, 1>{}, bufn);
-                        if constexpr (st == 1) { dma_group(d_tc, d_ch, std::integral_constant<int, 2>{}, bufn); d_advance(); }
+                        if constexpr (st == 1) { dma_group(d_tc, d_ch, std::integral_constant<int, 2>{}, bufn); t_n = d_tc.n; t_ch = d_ch; d_advance(); }
                         if constexpr (st == 3) dma_group(d_tc, d_ch, std::integral_constant<int, 0>{}, const_cast<float *>(bufc));
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -564,17 +662,36 @@ static int wino3_mode() {
 }
 bool conv3d_wino3_enabled() { return wino3_mode() != 0; }
 
-// Launches when the call fits the kernel (says so in *taken): stride 1, whole 4 x 8 x 8 tiles, 16-channel chunks on both halves
-// of a virtual concat, enough tiles to fill the chip; the fused head needs Cout = 32.
+// Does the F(2x2x2, 3x3x3) kernel take this call?  Stride 1, whole 4 x 8 x 8 tiles, 16-channel chunks on both halves of a virtual
+// concat, enough tiles to fill the chip; the fused head needs Cout = 32; the fused input norm (INAFF) a single input tensor and
+// the statistics instantiation (its consumer is a block of the same Instance/GroupNorm stage).
+static bool wino3_fits(const ConvWeights &w, const ConvCall &c) {
+    if (!wino3_mode() || !w.wp3_dev || w.stride != 1) return false;
+    if (c.head_out && (w.cout != 32 || c.stats || c.head_ncls < 1 || c.head_ncls > 4 || !c.head_w || !c.head_b)) return false;
+    if (c.in_scale && (c.C1 != 0 || !c.stats || c.head_out || !c.in_shift)) return false;
+    if (c.Di % 4 || c.Hi % 8 || c.Wi % 8 || c.C0 % 16 || c.C1 % 16 || w.cout % 32 || (c.C0 + c.C1) != w.cin_pad) return false;
+    const long tiles = (long)(c.Wi / 8) * (c.Hi / 8) * (c.Di / 4) * c.N;
+    if (tiles * (w.cout / 32) < 1024 || tiles >= (1l << 30)) return false;
+    if ((long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) >= (1l << 31)) return false;  // the per-lane part of a DMA address fits 32 bits
+    return true;
+}
+
+// Can the conv `w` of call shape `c` (N, Di, Hi, Wi, C0, stats set as it will be called) apply its producer's normalisation itself?
+bool conv3d_wino3_fuses_input_norm(const ConvWeights &w, const ConvCall &c) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("MI355_FUSE_NORM"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on) return false;
+    ConvCall t = c;
+    static const float dummy = 0.f;
+    t.in_scale = &dummy; t.in_shift = &dummy;
+    return wino3_fits(w, t);
+}
+
 int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name, bool *taken) {
     *taken = false;
-    if (!wino3_mode() || !w.wp3_dev || w.stride != 1) return MI355_OK;
-    if (c.head_out && (w.cout != 32 || c.stats || c.head_ncls < 1 || c.head_ncls > 4 || !c.head_w || !c.head_b)) return MI355_OK;
-    if (c.Di % 4 || c.Hi % 8 || c.Wi % 8 || c.C0 % 16 || c.C1 % 16 || w.cout % 32 || (c.C0 + c.C1) != w.cin_pad) return MI355_OK;
+    if (!wino3_fits(w, c)) return MI355_OK;
     const int tx = c.Wi / 8, ty = c.Hi / 8, tz = c.Di / 4;
     const long tiles = (long)tx * ty * tz * c.N;
-    if (tiles * (w.cout / 32) < 1024 || tiles >= (1l << 30)) return MI355_OK;
-    if ((long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) >= (1l << 31)) return MI355_OK;  // the per-lane part of a DMA address fits 32 bits
     Wino3Args a;
     a.in0 = c.in0; a.in1 = c.in1; a.wp = w.wp3_dev; a.bias = w.bias_dev; a.out = c.out; a.stats = c.stats;
     a.C0 = c.C0; a.C1 = c.C1; a.N = c.N; a.D = c.Di; a.H = c.Hi; a.W = c.Wi; a.Cout = w.cout;
@@ -583,6 +700,7 @@ int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, con
     a.div_tiles_per_n = make_fastdiv(tx * ty * tz);
     a.order = make_tile_order(tx, ty, tz);
     a.head_w = c.head_w; a.head_b = c.head_b; a.head_out = c.head_out; a.head_ncls = c.head_ncls;
+    a.in_scale = c.in_scale; a.in_shift = c.in_shift; a.in_slope = c.in_act == ACT_LRELU ? c.slope : 1.0f;
     float *zeros = nullptr;
     MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
     a.zeros = zeros;
@@ -591,6 +709,7 @@ int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, con
         MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
         MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
         MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
+        MI355_HIP(hipFuncSetAttribute((const void *)conv3_f32_wino3_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
         attr_set = true;
     }
     const int gy = w.cout / 32;
@@ -598,7 +717,10 @@ int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, con
     gx = gx < 8 ? 8 : (gx / 8) * 8;         // multiple of 8: blockIdx.x & 7 labels the XCD group
     const int need = (int)((tiles + 7) / 8) * 8;
     if (gx > need) gx = need;
-    if (c.head_out) {
+    if (c.in_scale) {
+        if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<2, true>";
+        hipLaunchKernelGGL((conv3_f32_wino3_kernel<2, true>), dim3(gx, gy), dim3(256), W3_LDS_BYTES, s, a);
+    } else if (c.head_out) {
         if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<1>";
         hipLaunchKernelGGL(conv3_f32_wino3_kernel<1>, dim3(gx, gy), dim3(256), W3_LDS_BYTES, s, a);
     } else if (c.stats) {

@@ -43,11 +43,16 @@ struct ConvCall {
     const float *head_w = nullptr, *head_b = nullptr;
     float *head_out = nullptr;
     int head_ncls = 0;
+    // in0 is the RAW conv output of the previous block: apply x * in_scale[n][c] + in_shift[n][c] (+ LeakyReLU when in_act) while
+    // staging it (only where conv3d_wino3_fuses_input_norm says so: the F(2x2x2,3x3x3) kernel normalises its brick in LDS)
+    const float *in_scale = nullptr, *in_shift = nullptr;
+    int in_act = ACT_NONE;
 };
 int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name = nullptr);
 // F(2x2x2, 3x3x3) kernel (conv3d_wino3.hip): launches when the call fits it and says so in *taken
 void pack_conv_weights_wino3(const float *w, int cin, int cin_pad, int cout, std::vector<float> &out);
 bool conv3d_wino3_enabled();
+bool conv3d_wino3_fuses_input_norm(const ConvWeights &w, const ConvCall &c);
 int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, const char **kernel_name, bool *taken);
 int conv3d_direct_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s);
 

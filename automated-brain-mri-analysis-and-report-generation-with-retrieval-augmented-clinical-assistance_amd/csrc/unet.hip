@@ -318,6 +318,10 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
             c.N = N; c.Di = Di; c.Hi = Hi; c.Wi = Wi; c.out = (float *)out; c.slope = net->slope;
             c.act = act; c.stats = stats_arg;
             if (head_logits_out) { c.head_w = net->head.w_dev; c.head_b = net->head.b_dev; c.head_ncls = net->head.ncls; c.head_out = head_logits_out; }
+            if (in_norm) {  // in0 is the previous block's raw conv output: the F(2x2x2,3x3x3) kernel normalises (+ LeakyReLU) its brick in LDS
+                c.in_scale = (const float *)(net->arena + pl.scale2_off); c.in_shift = (const float *)(net->arena + pl.shift2_off);
+                c.in_act = net->nonlin_first ? ACT_NONE : ACT_LRELU;
+            }
             const char *kname = nullptr;
             ProfScope ps(net, s, conv_kernel_name(L.w), flops, bytes);
             if (L.w.wp_dev) MI355_TRY(conv3d_mfma_f32(L.w, c, s, &kname));
@@ -341,16 +345,24 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
     return MI355_OK;
 }
 
-// Can block `L` (run-time Instance/GroupNorm) leave its normalisation to the next block `Ln` of the same stage?  fp16 only:
-// the consumer must be the register-staged pipelined stride-1 kernel (conv3d_f16_fuses_input_norm); the f32 path stages its
-// bricks by LDS-DMA and keeps the separate pass.  generic_UNet.py:62-72 is one expression, lrelu(instnorm(conv(x))).
+// Can block `L` (run-time Instance/GroupNorm) leave its normalisation to the next block `Ln` of the same stage?
+// generic_UNet.py:62-72 is one expression, lrelu(instnorm(conv(x))).  fp16: the consumer must be a kernel that normalises while
+// staging (conv3d_f16_fuses_input_norm: register-staged pipelined kernel or the LDS-DMA kernel).  fp32 (round 4): the consumer
+// must be a launch of the F(2x2x2,3x3x3) kernel, which normalises its brick in LDS (conv3d_wino3_fuses_input_norm).
 static bool can_defer_norm(const mi355_unet *net, const ConvLayer &L, const ConvLayer &Ln, int N, int Dl, int Hl, int Wl) {
-    if (net->dtype != MI355_F16 || !L.runtime_norm || L.is_stem == false && !L.wh.wp_dev) return false;
-    if (Ln.stride != 1 || Ln.is_stem || !Ln.wh.wp_dev || Ln.cin != L.cout) return false;
-    ConvCallH c;
+    if (!L.runtime_norm || Ln.stride != 1 || Ln.is_stem || Ln.cin != L.cout) return false;
+    if (net->dtype == MI355_F16) {
+        if ((!L.is_stem && !L.wh.wp_dev) || !Ln.wh.wp_dev) return false;
+        ConvCallH c;
+        c.C0 = L.cout; c.C1 = 0; c.N = N; c.Di = Dl; c.Hi = Hl; c.Wi = Wl;
+        c.stats = Ln.runtime_norm ? (double *)1 : nullptr;  // (only tested for null)
+        return conv3d_f16_fuses_input_norm(Ln.wh, c);
+    }
+    if (!Ln.w.wp3_dev) return false;
+    ConvCall c;
     c.C0 = L.cout; c.C1 = 0; c.N = N; c.Di = Dl; c.Hi = Hl; c.Wi = Wl;
-    c.stats = Ln.runtime_norm ? (double *)1 : nullptr;  // (only tested for null)
-    return conv3d_f16_fuses_input_norm(Ln.wh, c);
+    c.stats = Ln.runtime_norm ? (double *)1 : nullptr;
+    return conv3d_wino3_fuses_input_norm(Ln.w, c);
 }
 
 // x0: [N,D,H,W,cin_pad] already in the arena at pl.x0_off.  Returns the last decoder feature map.

@@ -293,6 +293,51 @@ np.savez(sys.argv[1], y=y, names=np.array(names))
     assert err <= 1.2e-2 * spread
 
 
+def test_f32_fused_input_norm_agrees_with_the_separate_pass(amd, gpu):
+    """Round 4: on the fp32 path the Instance/GroupNorm (+ LeakyReLU) of a stage's first conv is applied by the second conv when that
+    conv runs on the F(2x2x2,3x3x3) kernel, which normalises its brick in LDS (conv3_f32_wino3_kernel<2, true>): the same fp32
+    arithmetic as the separate norm_apply pass (one fma, max(y, slope y)), so the two builds agree to summation-order noise and
+    each is within the file's fp32 gate of the oracle.  The switch is read once per process: one child per setting."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import brats_amd
+sd, meta = brats_amd.synthetic.make_model("B", seed=7)
+net = brats_amd.UNet(sd, norm="group", num_groups=16)
+x = np.random.RandomState(1).standard_normal((2, 4, 64, 64, 64)).astype(np.float32)
+net.profile(True)
+y = net(torch.from_numpy(x).cuda()).cpu().numpy()
+prof = net.read_profile()
+np.savez(sys.argv[1], y=y, names=np.array(sorted(e["name"] for e in prof)), norm_launches=sum(e["launches"] for e in prof if e["name"].startswith("norm_apply")))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("1", "0"):
+            path = os.path.join(td, f"y{flag}.npz")
+            res = subprocess.run([sys.executable, "-c", code % root, path], env=dict(os.environ, MI355_FUSE_NORM=flag),
+                                 capture_output=True, text=True, timeout=600)
+            assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+            outs[flag] = np.load(path)
+    fused, plain = outs["1"], outs["0"]
+    assert "conv3_f32_wino3_kernel<2, true>" in list(fused["names"]), list(fused["names"])
+    assert "conv3_f32_wino3_kernel<2, true>" not in list(plain["names"])
+    assert int(fused["norm_launches"]) < int(plain["norm_launches"])     # the deferred blocks' separate passes are gone
+    sd, meta = amd.synthetic.make_model("B", seed=7)
+    x = np.random.RandomState(1).standard_normal((2, 4, 64, 64, 64)).astype(np.float32)
+    ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm="group", num_groups=16)).numpy()
+    _check_logits(fused["y"], ref, "64^3 B f32, norm fused into the consumer")
+    _check_logits(plain["y"], ref, "64^3 B f32, separate norm pass")
+    spread = float(ref.std())
+    err = float(np.abs(fused["y"] - plain["y"]).max())
+    print(f"PARITY fused-vs-separate norm (f32, B 64^3): {err / spread:.2e} x spread")
+    assert err <= LOGIT_REL_TOL * spread
+
+
 def test_sliding_window_f16_tta(amd, gpu):
     sd = _small_net(amd)
     net = amd.UNet(sd, norm="batch", dtype="f16")
