@@ -456,6 +456,12 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
             float *wr = stage + wave * (4 * W3_IMG) + (lane_e & 31) * W3_PITCH + 4 * (lane_e >> 5);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
+                // The accumulators are "redefined" by an empty asm at the top of every register pair: the 32 v_accvgpr_read of pair r
+                // cannot be hoisted above it.  A scheduling barrier alone did not hold them: hipcc read ~170 accumulator registers
+                // into VGPRs before the first staged write, which is what put every instantiation at the 256-VGPR limit with 7-10
+                // spilled loop invariants (without the epilogue the kernel needs 152 registers).
+#pragma unroll
+                for (int f = 0; f < 16; ++f) asm volatile("" : "+a"(acc[f]));
                 f32x2 P[2][4];  // [oy][xi_x]
 #pragma unroll
                 for (int fx = 0; fx < 4; ++fx) {
