@@ -1140,6 +1140,10 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
             const f32x4 bias = *(const f32x4 *)(p.bias + (int)blockIdx.y * 32 + (lane_e & 7) * 4);  // (lands during the transform)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
+                // (round 4: the accumulators are "redefined" by an empty asm per register pair, so that the pair's 32 v_accvgpr_read
+                //  cannot be hoisted above it - the scheduling barrier below alone did not hold them, see conv3d_wino3.hip)
+#pragma unroll
+                for (int f = 0; f < 16; ++f) asm volatile("" : "+a"(acc[f]));
                 f32x2 P[4][2];
 #pragma unroll
                 for (int fz = 0; fz < 4; ++fz) {
@@ -1270,6 +1274,10 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino2_kernel(Wino2Args pa) {
                 for (int c = 0; c < KMAX; ++c) part[mf][c] = f32x2{0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
+                // (round 4: the accumulators are "redefined" by an empty asm per register pair, so that the pair's 32 v_accvgpr_read
+                //  cannot be hoisted above it - the scheduling barrier below alone did not hold them, see conv3d_wino3.hip)
+#pragma unroll
+                for (int f = 0; f < 16; ++f) asm volatile("" : "+a"(acc[f]));
                 f32x2 P[4][2];
 #pragma unroll
                 for (int fz = 0; fz < 4; ++fz) {
