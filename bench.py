@@ -294,14 +294,26 @@ class CpuOracle:
         cfg = unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])
         if not self.logits:
             unet_ref.unet_forward(sd, self.x[:, :, :64, :64, :64], cfg)  # page in
-        n, t0 = 0, time.perf_counter()
-        while n < min_forwards or (time.perf_counter() - t0 < budget_s and n < 6):
-            out = unet_ref.unet_forward(sd, self.x, cfg)
-            n += 1
-        if name not in self.seconds or n > self.seconds[name][1]:
-            self.seconds[name] = ((time.perf_counter() - t0) / n, n)
+        timed = min_forwards > 1 or budget_s > 0
+        all_threads = torch.get_num_threads()
+        if self.cores is None:
+            self.cores = all_threads
+        # the TIMED forwards (cpu_baseline) use every core the host gives torch, as SURVEY.md 8d asks; the forwards that only serve
+        # as parity references run with 16 threads - on the 128-core GPU box torch's conv3d is faster that way (2.1 s against 3.9 s)
+        if not timed and all_threads > 16:
+            torch.set_num_threads(16)
+        try:
+            n, t0 = 0, time.perf_counter()
+            while n < min_forwards or (time.perf_counter() - t0 < budget_s and n < 6):
+                out = unet_ref.unet_forward(sd, self.x, cfg)
+                n += 1
+            if timed:
+                self.seconds[name] = ((time.perf_counter() - t0) / n, n)
+            elif name not in self.seconds:
+                self.seconds[name] = ((time.perf_counter() - t0) / n, 0)   # (0 timed forwards: a parity run, 16 threads)
+        finally:
+            torch.set_num_threads(all_threads)
         self.logits[(name, seed)] = out
-        self.cores = torch.get_num_threads()
         return out
 
     def time_8_threads(self, name, seed):
@@ -630,7 +642,7 @@ def main(argv=None):
                           f"{cfgd['tiles_per_volume'] * cfgd['mirrors'] * len(cfgd['models'])} forwards of one volume",
                    seconds_per_volume_est=round(est_volume_s, 2))
         if "B" in oracle.seconds:
-            cpu["model_B_forward_s"] = round(oracle.seconds["B"][0], 2)
+            cpu["model_B_forward_s_16_threads"] = round(oracle.seconds["B"][0], 2)
 
     out = {
         "metric": "BraTS volumes/sec (4-modality 240x240x155)", "value": main_res["volumes_per_s"], "unit": "volumes/s",
