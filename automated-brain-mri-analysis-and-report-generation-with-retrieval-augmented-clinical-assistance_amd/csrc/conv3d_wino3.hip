@@ -69,6 +69,9 @@ __device__ unsigned long long w3_stamps[1024 * 16];
 #define W3_ACC(slot, a, b)
 #define W3_CNT(slot)
 #endif
+#ifndef MI355_W3_PIN
+#define MI355_W3_PIN 1   // epilogue phase 1: the accumulator reads are pinned every MI355_W3_PIN register pairs (see there)
+#endif
 #ifndef MI355_W3_ABL
 #define MI355_W3_ABL 0  // ablation bits (probe only, results wrong): 1 no epilogue, 4 no brick DMA, 8 no weight loads, 16 no input transform, 32 no stores
 #endif
@@ -460,8 +463,10 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                 // cannot be hoisted above it.  A scheduling barrier alone did not hold them: hipcc read ~170 accumulator registers
                 // into VGPRs before the first staged write, which is what put every instantiation at the 256-VGPR limit with 7-10
                 // spilled loop invariants (without the epilogue the kernel needs 152 registers).
+                if ((r / 2) % MI355_W3_PIN == 0) {
 #pragma unroll
-                for (int f = 0; f < 16; ++f) asm volatile("" : "+a"(acc[f]));
+                    for (int f = 0; f < 16; ++f) asm volatile("" : "+a"(acc[f]));
+                }
                 f32x2 P[2][4];  // [oy][xi_x]
 #pragma unroll
                 for (int fx = 0; fx < 4; ++fx) {
