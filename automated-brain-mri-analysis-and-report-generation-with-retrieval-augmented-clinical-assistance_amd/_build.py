@@ -26,7 +26,7 @@ CSRC = PKG_DIR / "csrc"
 LIB_DIR = Path(os.environ["MI355_LIB_DIR"]).resolve() if os.environ.get("MI355_LIB_DIR") else PKG_DIR.parent / "lib"
 OBJ_DIR = LIB_DIR / "obj"
 LIB_PATH = LIB_DIR / "libmi355_nnunet.so"
-SOURCES = ["conv3d.hip", "conv3d_wino3.hip", "conv3d_f16.hip", "conv3d_f16_s2.hip", "conv_stem.hip", "tconv.hip", "elementwise.hip", "extras.hip", "unet.hip"]
+SOURCES = ["conv3d.hip", "conv3d_wino3.hip", "conv3d_f16.hip", "conv3d_f16_s2.hip", "conv_stem.hip", "tconv.hip", "elementwise.hip", "extras.hip", "resample.hip", "unet.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-pass-failed"]
 
 

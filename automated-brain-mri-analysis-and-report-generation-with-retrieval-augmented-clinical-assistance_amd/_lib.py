@@ -29,6 +29,7 @@ EXPORTS = [
     "mi355_last_conv_kernel",
     "mi355_conv3d_sums_ndhwc",
     "mi355_sw_partial_folds", "mi355_sw_finish_folds",
+    "mi355_resize_axis", "mi355_clip_to_range_of", "mi355_threshold_ge", "mi355_mask_to_float",
 ]
 
 
@@ -124,6 +125,10 @@ def load():
     lib.mi355_cosine_topk.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, c_int32_p, c_float_p, vp]
     lib.mi355_crop_mask.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, c_int32_p, vp]
     lib.mi355_label_stats.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), vp]
+    lib.mi355_resize_axis.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, vp]
+    lib.mi355_clip_to_range_of.argtypes = [vp, C.c_int64, C.c_int64, vp, C.c_int64, vp]
+    lib.mi355_threshold_ge.argtypes = [vp, C.c_float, vp, C.c_int64, vp]
+    lib.mi355_mask_to_float.argtypes = [vp, vp, C.c_int64, vp]
     lib.mi355_profile_enable.argtypes = [vp, C.c_int]
     lib.mi355_profile_read.argtypes = [vp, C.POINTER(ProfEntry), C.c_int]
     _lib = lib

@@ -23,7 +23,7 @@ int bind_device();
 // mutex and never freed per call; `zeroed` buffers are cleared when (re)allocated.  Work that uses a slot is ordered
 // by the caller's stream: one stream at a time per process ("Stream semantics").
 enum ScratchSlot { SCR_ARENA = 0, SCR_SW_AGG, SCR_SPLITK_F32, SCR_SPLITK_F16, SCR_ZEROS, SCR_ZERO_BIAS, SCR_SMALL, SCR_TOPK,
-                   SCR_CROP, SCR_ZSCORE, SCR_COUNT };
+                   SCR_CROP, SCR_ZSCORE, SCR_RESAMPLE, SCR_RESAMPLE_MM, SCR_COUNT };
 int device_scratch(int slot, size_t bytes, void **out, bool zeroed = false);
 
 #define MI355_HIP(expr)                                                                    \

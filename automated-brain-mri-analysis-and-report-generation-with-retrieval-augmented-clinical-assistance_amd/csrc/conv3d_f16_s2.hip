@@ -367,7 +367,7 @@ int conv3d_f16_s2dma(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, c
         if (c.stats) return launch(conv3_f16_s2dma_kernel<true, 64>, 2);
         return launch(conv3_f16_s2dma_kernel<false, 64>, 3);
     }
-    if (kernel_name) *kernel_name = c.stats ? "conv3_f16_s2dma_kernel<true>" : "conv3_f16_s2dma_kernel<false>";
+    if (kernel_name) *kernel_name = c.stats ? "conv3_f16_s2dma_kernel<true, 128>" : "conv3_f16_s2dma_kernel<false, 128>";
     if (c.stats) return launch(conv3_f16_s2dma_kernel<true, 128>, 0);
     return launch(conv3_f16_s2dma_kernel<false, 128>, 1);
 }

@@ -732,13 +732,13 @@ int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, con
         if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<2, true>";
         hipLaunchKernelGGL((conv3_f32_wino3_kernel<2, true>), dim3(gx, gy), dim3(256), W3_LDS_BYTES, s, a);
     } else if (c.head_out) {
-        if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<1>";
+        if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<1, false>";
         hipLaunchKernelGGL(conv3_f32_wino3_kernel<1>, dim3(gx, gy), dim3(256), W3_LDS_BYTES, s, a);
     } else if (c.stats) {
-        if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<2>";
+        if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<2, false>";
         hipLaunchKernelGGL(conv3_f32_wino3_kernel<2>, dim3(gx, gy), dim3(256), W3_LDS_BYTES, s, a);
     } else {
-        if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<0>";
+        if (kernel_name) *kernel_name = "conv3_f32_wino3_kernel<0, false>";
         hipLaunchKernelGGL(conv3_f32_wino3_kernel<0>, dim3(gx, gy), dim3(256), W3_LDS_BYTES, s, a);
     }
     MI355_HIP(hipGetLastError());

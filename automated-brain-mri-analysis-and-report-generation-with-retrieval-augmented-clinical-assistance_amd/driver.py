@@ -136,6 +136,9 @@ def predict_case_single_threaded(model: LoadedModel, list_of_files, output_file,
     probs = predictor.predict_folds(model.nets, data, model.patch_size, step_size, do_tta, (0, 1, 2), True,
                                     model.nonlin)
     print(f"Ensembling {len(model.nets)} folds")
+    # save_segmentation_nifti_from_softmax resamples the probabilities back to the shape after cropping (order 1; driver :131-138):
+    # a no-op unless preprocessing resampled (never for BraTS, 1 mm -> 1 mm)
+    probs = preprocessing.resample_probabilities_for_export(probs, props)
     lo = [b[0] for b in props["crop_bbox"]]
     seg = ops.regions_to_labels(probs, (1, 2, 3) if model.folder.regions else None, lo, props["original_size_of_raw_data"])
     torch.cuda.synchronize()
@@ -302,10 +305,15 @@ def run_both_models(model_dirs, input_folder, output_folder, folds, do_tta, step
         for mi in order:
             model = models[mi]
             if model.folder.plans is not plans0:
+                # both members predict from ONE preprocessed tensor: their plans must ask for the same preprocessing of this case
                 preprocessing.check_plans(model.folder.plans, cur_raw_channels)
-                preprocessing.check_spacing(model.folder.plans, tuple(reversed(cur_like.zooms)), data.shape[1:])
+                zyx = tuple(reversed(cur_like.zooms))
+                if preprocessing.check_spacing(model.folder.plans, zyx, props["size_after_cropping"]) != \
+                        preprocessing.check_spacing(plans0, zyx, props["size_after_cropping"]):
+                    raise preprocessing.UnsupportedPlansError("the two ensemble members' plans resample this case to different grids")
             print(f"Predicting {case_name} with model {mi + 1} ({len(model.nets)} folds)")
             probs = predictor.predict_folds(model.nets, data, model.patch_size, step_size, do_tta, (0, 1, 2), True, model.nonlin)
+            probs = preprocessing.resample_probabilities_for_export(probs, props)   # (a no-op unless preprocessing resampled)
             lo = [b[0] for b in props["crop_bbox"]]
             segs[mi] = ops.regions_to_labels(probs, (1, 2, 3) if model.folder.regions else None, lo, props["original_size_of_raw_data"])
         ens = evaluate.convert_labels(ops.label_ensemble(segs[0], segs[1]), label_format)

@@ -96,6 +96,56 @@ def zscore_masked_(vol, mask):
     return vol
 
 
+def resize_axis(x, axis: int, n_out: int, order: int):
+    """One 1-D resampling pass along ``axis`` of a contiguous CUDA fp32 tensor (``mi355_resize_axis``): half-pixel-centred grid,
+    edge replication, interpolation order 0 / 1 / 3 - skimage.transform.resize(order, mode='edge', anti_aliasing=False) along one
+    axis, before its clipping."""
+    import torch
+    x = _require_cuda(x, torch.float32, "x")
+    axis = axis % x.dim()
+    n_in = int(x.shape[axis])
+    if int(n_out) == n_in:
+        return x
+    outer = int(np.prod(x.shape[:axis], dtype=np.int64)) if axis > 0 else 1
+    inner = int(np.prod(x.shape[axis + 1:], dtype=np.int64)) if axis + 1 < x.dim() else 1
+    out = torch.empty(tuple(x.shape[:axis]) + (int(n_out),) + tuple(x.shape[axis + 1:]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mi355_resize_axis(x.data_ptr(), out.data_ptr(), outer, n_in, int(n_out), inner, int(order), _stream(x)),
+               "mi355_resize_axis")
+    return out
+
+
+def clip_to_range_of_(x, ref, group_dims: int):
+    """In place: every group of ``x`` (its first ``group_dims`` axes index the groups) clipped to [min, max] of the same group of
+    ``ref`` (skimage's resize clips its output to the range of its input)."""
+    import torch
+    x = _require_cuda(x, torch.float32, "x")
+    ref = _require_cuda(ref, torch.float32, "ref")
+    if tuple(x.shape[:group_dims]) != tuple(ref.shape[:group_dims]):
+        raise ValueError("clip_to_range_of_: group shapes differ")
+    groups = int(np.prod(x.shape[:group_dims], dtype=np.int64)) if group_dims else 1
+    _lib.check(_lib.load().mi355_clip_to_range_of(x.data_ptr(), groups, x.numel() // groups, ref.data_ptr(), ref.numel() // groups,
+                                                  _stream(x)), "mi355_clip_to_range_of")
+    return x
+
+
+def mask_to_float(mask):
+    """fp32 indicator (1.0 / 0.0) of a uint8 mask (``mi355_mask_to_float``)."""
+    import torch
+    mask = _require_cuda(mask, torch.uint8, "mask")
+    out = torch.empty(mask.shape, dtype=torch.float32, device=mask.device)
+    _lib.check(_lib.load().mi355_mask_to_float(mask.data_ptr(), out.data_ptr(), mask.numel(), _stream(mask)), "mi355_mask_to_float")
+    return out
+
+
+def threshold_ge(x, thr: float):
+    """uint8 mask ``x >= thr`` (``mi355_threshold_ge``)."""
+    import torch
+    x = _require_cuda(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().mi355_threshold_ge(x.data_ptr(), float(thr), out.data_ptr(), x.numel(), _stream(x)), "mi355_threshold_ge")
+    return out
+
+
 def conv3d_ndhwc(x, weight, bias=None, stride=1, act=0, slope=0.01, impl="mfma"):
     """Single conv (test entry point). x: CUDA fp32 or fp16 [N,D,H,W,Cin]; weight: numpy [Cout,Cin,3,3,3]."""
     import torch

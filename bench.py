@@ -53,7 +53,8 @@ DICE_GATE = 0.999  # BASELINE.json north_star: Dice against the reference CPU ou
 EXECUTED_RATIO = {"conv3_f32_wino_kernel": 2.0 / 3.0, "conv3_f32_wino2_kernel<0>": 4.0 / 9.0, "conv3_f32_wino2_kernel<1>": 4.0 / 9.0,
                   "conv3_f32_wino2_kernel<2>": 4.0 / 9.0,
                   # F(2x2x2,3x3x3): 64 multiplies per 2x2x2 outputs and (cin, cout) instead of 8 * 27
-                  "conv3_f32_wino3_kernel<0>": 8.0 / 27.0, "conv3_f32_wino3_kernel<1>": 8.0 / 27.0, "conv3_f32_wino3_kernel<2>": 8.0 / 27.0}
+                  "conv3_f32_wino3_kernel<0, false>": 8.0 / 27.0, "conv3_f32_wino3_kernel<1, false>": 8.0 / 27.0, "conv3_f32_wino3_kernel<2, false>": 8.0 / 27.0,
+                  "conv3_f32_wino3_kernel<2, true>": 8.0 / 27.0}
 
 WORKLOADS = {
     2: dict(models=[("A", 7)], tta=False, dtype="f32",

@@ -19,6 +19,8 @@
  *   mi355_prob_mean          archived/kaist_original_inference.py:30-32 (nnUNet_ensemble: mean of two softmax volumes)
  *   mi355_zscore_masked      trainer.preprocess_patient -> nonCT + use_mask_for_norm normalisation,
  *                            called at run_brats2021_inference_singlethread.py:89
+ *   mi355_resize_axis        trainer.preprocess_patient -> resample_patient (same call) and the resampling inside
+ *                            save_segmentation_nifti_from_softmax (:131-138, :144-156)
  *
  * Conventions: every function returns 0 on success and a negative code on failure;
  * mi355_last_error() gives the message of the calling thread's last failure.
@@ -180,6 +182,25 @@ int mi355_cosine_topk(const float *vectors_dev, const float *query_dev, int N, i
  * bbox_host = {z_lo, z_hi, y_lo, y_hi, x_lo, x_hi} (hi exclusive).  vol_dev [C][Z][Y][X] fp32, mask_dev [Z][Y][X] uint8.
  * Synchronous (returns the box). */
 int mi355_crop_mask(const float *vol_dev, int C, int Z, int Y, int X, uint8_t *mask_dev, int32_t *bbox_host, void *stream);
+
+/* Resampling between voxel grids (round 4): step 4 of trainer.preprocess_patient (run_brats2021_inference_singlethread.py:89 ->
+ * nnU-Net v1 resample_patient: data order 3, mask order 1, a low-resolution axis separately with order 0) and the resampling inside
+ * save_segmentation_nifti_from_softmax(..., order=1, force_separate_z=None, interpolation_order_z=0) (driver :131-138, :144-156).
+ * One 1-D pass: in_dev viewed as [outer][n_in][inner] fp32 -> out_dev [outer][n_out][inner], sampled on the half-pixel-centred
+ * grid x_in = (x_out + 0.5) * n_in / n_out - 0.5 with edge replication - what skimage.transform.resize(order, mode='edge',
+ * anti_aliasing=False) / scipy.ndimage.zoom(order, mode='nearest', grid_mode=True) do along one axis.  order 0 (nearest), 1 (linear)
+ * or 3 (cubic B-spline incl. its prefilter).  A tensor-product resize is one pass per axis, in any order.  Asynchronous on `stream`. */
+int mi355_resize_axis(const float *in_dev, float *out_dev, int64_t outer, int n_in, int n_out, int64_t inner, int order,
+                      void *stream);
+/* x[g][0..n_per_group) clipped to [min, max] of ref[g][0..ref_per_group), g < groups (skimage's resize clips its output to the
+ * range of its input image: per channel for a 3-D resize, per slice in nnU-Net's separate-z mode). */
+int mi355_clip_to_range_of(float *x_dev, int64_t groups, int64_t n_per_group, const float *ref_dev, int64_t ref_per_group,
+                           void *stream);
+/* out[i] = x[i] >= thr (batchgenerators resize_segmentation: a label survives where its linearly resized indicator is >= 0.5;
+ * here the inside-the-brain mask that use_mask_for_norm reads after resampling). */
+int mi355_threshold_ge(const float *x_dev, float thr, uint8_t *out_dev, int64_t n, void *stream);
+/* out[i] = mask[i] != 0 ? 1.0f : 0.0f (the indicator resize_segmentation resizes). */
+int mi355_mask_to_float(const uint8_t *mask_dev, float *out_dev, int64_t n, void *stream);
 
 /* Per-label voxel statistics of a label map [d0][d1][d2] (feature_extraction/utils.py:167-216: the integers behind
  * get_tumor_masks + calculate_volume + get_centroid + get_bounding_box).  stats_host[label * 10 + f], label < K <= 8:

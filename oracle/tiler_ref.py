@@ -206,6 +206,125 @@ def preprocess_case(raw):
     return data, props
 
 
+# --------------------------------------------------------------------------- resampling (rows P step 4 and E)
+# PARITY UNPINNED twice over: nnU-Net v1's resample_patient / resample_data_or_seg (un-vendored) call
+# skimage.transform.resize(order, mode='edge', anti_aliasing=False) and batchgenerators' resize_segmentation, and neither
+# package is in this image.  skimage >= 0.19 implements that resize as scipy.ndimage.zoom(order, mode='nearest', grid_mode=True)
+# followed by a clip to the input's range; earlier releases sample the same half-pixel-centred grid through map_coordinates.
+# scipy IS here, so the restatement below calls it.
+RESAMPLING_SEPARATE_Z_ANISO_THRESHOLD = 3
+
+
+def get_do_separate_z(spacing, anisotropy_threshold=RESAMPLING_SEPARATE_Z_ANISO_THRESHOLD):
+    return (np.max(spacing) / np.min(spacing)) > anisotropy_threshold
+
+
+def get_lowres_axis(new_spacing):
+    return np.where(max(new_spacing) / np.array(new_spacing) == 1)[0]  # the axis (axes) with the largest spacing
+
+
+def skimage_resize(img, new_shape, order):
+    """skimage.transform.resize(img, new_shape, order, mode='edge', anti_aliasing=False) (clip=True, float input)."""
+    from scipy.ndimage import zoom
+    img = np.asarray(img, dtype=np.float64)
+    factors = [float(n) / float(o) for n, o in zip(new_shape, img.shape)]
+    out = zoom(img, factors, order=order, mode="nearest", grid_mode=True)
+    assert tuple(out.shape) == tuple(int(v) for v in new_shape), (out.shape, new_shape)
+    return np.clip(out, img.min(), img.max())
+
+
+def resize_segmentation(seg, new_shape, order):
+    """batchgenerators.augmentations.utils.resize_segmentation: per label a linearly resized indicator, kept where >= 0.5."""
+    if order == 0:
+        return skimage_resize(seg.astype(float), new_shape, 0).astype(seg.dtype)
+    out = np.zeros(new_shape, dtype=seg.dtype)
+    for c in np.unique(seg):
+        m = skimage_resize((seg == c).astype(float), new_shape, order)
+        out[m >= 0.5] = c
+    return out
+
+
+def resample_data_or_seg(data, new_shape, is_seg, axis=None, order=3, do_separate_z=False, order_z=0):
+    """nnunet.preprocessing.preprocessing.resample_data_or_seg ([C, z, y, x] in and out)."""
+    from scipy.ndimage import map_coordinates
+    assert data.ndim == 4
+    resize_fn = resize_segmentation if is_seg else skimage_resize
+    shape = np.array(data[0].shape)
+    new_shape = np.array(new_shape)
+    if not np.any(shape != new_shape):
+        return data
+    dtype = data.dtype
+    data = data.astype(float)
+    if do_separate_z:
+        assert len(axis) == 1
+        ax = int(axis[0])
+        new_2d = [int(v) for i, v in enumerate(new_shape) if i != ax]
+        chans = []
+        for c in range(data.shape[0]):
+            slices = [resize_fn(np.take(data[c], k, axis=ax), new_2d, order) for k in range(shape[ax])]
+            vol = np.stack(slices, ax)
+            if shape[ax] != new_shape[ax]:
+                scale = [float(o) / float(n) for o, n in zip(vol.shape, new_shape)]
+                grid = np.mgrid[:new_shape[0], :new_shape[1], :new_shape[2]].astype(float)
+                coords = np.array([scale[i] * (grid[i] + 0.5) - 0.5 for i in range(3)])
+                assert not is_seg or order_z == 0
+                vol = map_coordinates(vol, coords, order=order_z, mode="nearest")
+            chans.append(vol[None])
+        return np.vstack(chans).astype(dtype)
+    return np.vstack([resize_fn(data[c], new_shape, order)[None] for c in range(data.shape[0])]).astype(dtype)
+
+
+def resample_plan(shape, original_spacing, target_spacing, force_separate_z=None,
+                  separate_z_anisotropy_threshold=RESAMPLING_SEPARATE_Z_ANISO_THRESHOLD):
+    """The decisions of nnunet resample_patient: (new_shape, do_separate_z, axis)."""
+    new_shape = np.round((np.array(original_spacing) / np.array(target_spacing)).astype(float) * np.array(shape)).astype(int)
+    if force_separate_z is not None:
+        do_separate_z = force_separate_z
+        axis = get_lowres_axis(original_spacing) if force_separate_z else None
+    elif get_do_separate_z(original_spacing, separate_z_anisotropy_threshold):
+        do_separate_z, axis = True, get_lowres_axis(original_spacing)
+    elif get_do_separate_z(target_spacing, separate_z_anisotropy_threshold):
+        do_separate_z, axis = True, get_lowres_axis(target_spacing)
+    else:
+        do_separate_z, axis = False, None
+    if axis is not None and len(axis) != 1:   # (3: isotropic; 2: e.g. (0.24, 1.25, 1.25) - not resampled separately)
+        do_separate_z = False
+    return tuple(int(v) for v in new_shape), bool(do_separate_z), axis
+
+
+def preprocess_case_resampled(raw, original_spacing, target_spacing):
+    """trainer.preprocess_patient (driver :89) INCLUDING step 4: crop, resample data (order 3) and the inside mask (order 1; the
+    low-resolution axis separately with order 0 when the spacing is anisotropic beyond 3), masked z-score on the new grid."""
+    raw = np.asarray(raw, dtype=np.float32)
+    cropped, inside, bbox = crop_to_nonzero(raw)
+    seg = np.where(inside, 0, -1).astype(np.float32)[None]
+    new_shape, sep, axis = resample_plan(cropped.shape[1:], original_spacing, target_spacing)
+    data = resample_data_or_seg(cropped, new_shape, False, axis, 3, sep, order_z=0)
+    seg = resample_data_or_seg(seg, new_shape, True, axis, 1, sep, order_z=0)
+    data = normalize_noct_masked(data, seg[0] >= 0)
+    props = dict(crop_bbox=bbox, original_size_of_raw_data=tuple(raw.shape[1:]), size_after_cropping=tuple(cropped.shape[1:]),
+                 size_after_resampling=tuple(new_shape), original_spacing=tuple(float(v) for v in original_spacing),
+                 spacing_after_resampling=tuple(float(v) for v in target_spacing))
+    return data, props
+
+
+def export_resample_probs(probs, props, order=1, order_z=0):
+    """The resampling inside save_segmentation_nifti_from_softmax(order=1, force_separate_z=None, interpolation_order_z=0)
+    (driver :131-138, :144-156): class probabilities on the resampled grid -> the shape after cropping."""
+    target = tuple(props["size_after_cropping"])
+    if tuple(probs.shape[1:]) == target:
+        return probs
+    if get_do_separate_z(props["original_spacing"]):
+        sep, axis = True, get_lowres_axis(props["original_spacing"])
+    elif get_do_separate_z(props["spacing_after_resampling"]):
+        sep, axis = True, get_lowres_axis(props["spacing_after_resampling"])
+    else:
+        sep, axis = False, None
+    if axis is not None and len(axis) != 1:
+        sep = False
+    return resample_data_or_seg(probs, target, False, axis, order, sep, order_z=order_z)
+
+
 # --------------------------------------------------------------------------- metric (SURVEY 8d)
 def dice(a, b, eps=1e-8):
     """evaluate_segmentation.py:181-195 calculate_metrics_binary Dice."""

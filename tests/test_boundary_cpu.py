@@ -166,10 +166,12 @@ def test_plans_are_checked_not_assumed(amd):
     pp, ck = amd.preprocessing, amd.checkpoint
     plans = ck.default_brats_plans()
     assert pp.check_plans(plans, 4) == [True] * 4 and pp.check_plans(None, 4) == [True] * 4
-    pp.check_spacing(plans, (1.0, 1.0, 1.0), (140, 171, 137))
-    pp.check_spacing(plans, (1.0, 1.0004, 1.0), (140, 171, 137))      # nnU-Net: round(spacing ratio * shape) == shape -> no resample
-    with pytest.raises(pp.UnsupportedPlansError, match="resampl"):
-        pp.check_spacing(plans, (2.0, 2.0, 2.0), (78, 120, 120))       # a 2 mm header (e.g. an api.py upload)
+    assert pp.check_spacing(plans, (1.0, 1.0, 1.0), (140, 171, 137)) is None
+    assert pp.check_spacing(plans, (1.0, 1.0004, 1.0), (140, 171, 137)) is None   # nnU-Net: round(spacing ratio * shape) == shape -> no resample
+    # round 4: a grid the plans would resample is no longer refused - check_spacing returns nnU-Net's resampling decisions
+    assert pp.check_spacing(plans, (2.0, 2.0, 2.0), (78, 120, 120)) == ((156, 240, 240), False, None, (1.0, 1.0, 1.0))   # a 2 mm header (e.g. an api.py upload)
+    assert pp.check_spacing(plans, (5.0, 1.0, 1.0), (30, 120, 100)) == ((150, 120, 100), True, 0, (1.0, 1.0, 1.0))       # thick slices: z separately
+    assert pp.resample_plan((30, 120, 100), (1.25, 1.25, 0.24), (1.0, 1.0, 1.0))[1:] == (False, None)                      # two axes share the largest spacing
     with pytest.raises(pp.UnsupportedPlansError, match="transpose_forward"):
         pp.check_plans({**plans, "transpose_forward": [2, 0, 1]}, 4)
     with pytest.raises(pp.UnsupportedPlansError, match="CT"):
@@ -179,9 +181,8 @@ def test_plans_are_checked_not_assumed(amd):
     mixed = pp.check_plans({**plans, "use_mask_for_norm": {0: True, 1: False, 2: True, 3: False}}, 4)
     assert mixed == [True, False, True, False]
     other = {**plans, "plans_per_stage": {0: {**plans["plans_per_stage"][0], "current_spacing": np.array([2.0, 1.0, 1.0])}}}
-    pp.check_spacing(other, (2.0, 1.0, 1.0), (70, 171, 137))
-    with pytest.raises(pp.UnsupportedPlansError):
-        pp.check_spacing(other, (1.0, 1.0, 1.0), (140, 171, 137))
+    assert pp.check_spacing(other, (2.0, 1.0, 1.0), (70, 171, 137)) is None
+    assert pp.check_spacing(other, (1.0, 1.0, 1.0), (140, 171, 137)) == ((70, 171, 137), False, None, (2.0, 1.0, 1.0))
 
 
 def test_worker_protocol_without_a_gpu(amd, tmp_path, monkeypatch):

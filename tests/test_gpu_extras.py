@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import driver_ref, extras_ref
+from oracle import driver_ref, extras_ref, tiler_ref, unet_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -130,3 +130,80 @@ def test_tumor_region_features(amd, gpu, present):
         else:
             for k in "xyz":
                 assert abs(got[name]["centroid"][k] - want[name]["centroid"][k]) <= 1e-9, (name, k)
+
+
+# --------------------------------------------------------------------------- resampling (round 4)
+@pytest.mark.parametrize("order", [0, 1, 3])
+@pytest.mark.parametrize("axis,n_out", [(3, 37), (3, 11), (2, 40), (1, 9), (1, 30)])
+def test_resize_axis_matches_scipy_zoom(amd, gpu, order, axis, n_out):
+    """mi355_resize_axis against scipy.ndimage.zoom(order, mode='nearest', grid_mode=True) along one axis (what
+    skimage.transform.resize(order, mode='edge', anti_aliasing=False) computes before its clip): up- and down-sampling along x, y
+    and z of a [C, Z, Y, X] tensor, nearest / linear / cubic B-spline (prefilter with scipy's 12-sample edge padding)."""
+    from scipy.ndimage import zoom
+    rs = np.random.RandomState(3)
+    x = (rs.standard_normal((2, 14, 19, 23)) * 50 + 100).astype(np.float32)
+    factors = [1.0, 1.0, 1.0, 1.0]
+    factors[axis] = n_out / x.shape[axis]
+    ref = zoom(x.astype(np.float64), factors, order=order, mode="nearest", grid_mode=True)
+    got = amd.ops.resize_axis(torch.from_numpy(x).to(gpu), axis, n_out, order).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= (0.0 if order == 0 else 2e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", [
+    dict(shape=(20, 24, 18), new=(31, 24, 27), sep=False, axis=None),     # isotropic-ish: 3-D cubic resize, clip per channel
+    dict(shape=(12, 30, 28), new=(36, 25, 33), sep=True, axis=0),         # thick slices: cubic in plane, nearest along z
+    dict(shape=(26, 9, 22), new=(20, 27, 22), sep=True, axis=1),          # the low-resolution axis is y
+    dict(shape=(20, 24, 18), new=(10, 12, 9), sep=False, axis=None),      # down-sampling
+])
+def test_resample_data_and_mask_match_the_oracle(amd, gpu, case):
+    """preprocessing.resample_data_or_seg (device) against oracle/tiler_ref.resample_data_or_seg (nnU-Net v1's function restated on
+    scipy; PARITY UNPINNED): image data with order 3 (+ skimage's clip to the input's range: per channel, per slice in the
+    separate-z mode) and the inside mask through resize_segmentation's rule (linear indicator >= 0.5)."""
+    pp = amd.preprocessing
+    rs = np.random.RandomState(11)
+    from scipy.ndimage import gaussian_filter
+    x = np.stack([gaussian_filter(rs.standard_normal(case["shape"]), 1.5) * 300 + 500 * (c + 1) for c in range(3)]).astype(np.float32)
+    axis = None if case["axis"] is None else np.array([case["axis"]])
+    ref = tiler_ref.resample_data_or_seg(x, case["new"], False, axis, 3, case["sep"], order_z=0)
+    got = pp.resample_data_or_seg(torch.from_numpy(x).to(gpu), case["new"], 3, case["sep"], case["axis"], 0).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+    zz, yy, xx = np.meshgrid(*[np.arange(n) for n in case["shape"]], indexing="ij")
+    inside = (((zz - case["shape"][0] / 2) / (case["shape"][0] * 0.4)) ** 2 + ((yy - case["shape"][1] / 2) / (case["shape"][1] * 0.35)) ** 2 +
+              ((xx - case["shape"][2] / 2) / (case["shape"][2] * 0.45)) ** 2) <= 1.0
+    seg = np.where(inside, 0, -1).astype(np.float32)[None]
+    ref_m = tiler_ref.resample_data_or_seg(seg, case["new"], True, axis, 1, case["sep"], order_z=0)[0] >= 0
+    got_m = pp.resample_data_or_seg(torch.from_numpy(inside.astype(np.float32))[None].to(gpu), case["new"], 1, case["sep"], case["axis"], 0,
+                                    is_mask=True)[0].cpu().numpy().astype(bool)
+    # (the indicator is resized in fp32 here and in fp64 there: a voxel whose value is 0.5 to the last bit may fall either way)
+    assert (got_m != ref_m).sum() <= 2, int((got_m != ref_m).sum())
+
+
+@pytest.mark.parametrize("spacing", [(2.0, 2.0, 2.0), (4.0, 1.0, 1.0)])
+def test_preprocess_predict_export_with_resampling_matches_the_oracle(amd, gpu, spacing):
+    """The whole path on a case whose grid is NOT the plans' grid (never BraTS; e.g. a 2 mm upload through api.py): crop ->
+    resample data (order 3) + mask (order 1) to 1 mm -> masked z-score -> sliding window -> probabilities resampled back with
+    order 1 (driver :131-138) -> region labels pasted at the crop box, against the oracle's restatement of the same steps."""
+    sd, _ = amd.synthetic.make_model("A", seed=21, num_pool=2, max_feat=64)
+    net = amd.UNet(sd, norm="batch")
+    patch = (32, 32, 32)
+    shape = tuple(int(round(s / f)) for s, f in zip((48, 56, 44), spacing))
+    raw = amd.synthetic.make_volume(seed=9, shape=shape)
+    plans = amd.checkpoint.default_brats_plans(patch)
+    data, props = amd.preprocessing.preprocess_case(raw, gpu, plans=plans, spacing_zyx=spacing)
+    ref_data, ref_props = tiler_ref.preprocess_case_resampled(raw, spacing, (1.0, 1.0, 1.0))
+    assert tuple(data.shape) == tuple(ref_data.shape) and props["size_after_resampling"] == ref_props["size_after_resampling"]
+    assert props["crop_bbox"] == ref_props["crop_bbox"] and props["size_after_cropping"] == ref_props["size_after_cropping"]
+    assert np.abs(data.cpu().numpy() - ref_data).max() <= 2e-3       # z-scored values (the mask may differ in a voxel or two: see above)
+    probs = amd.predictor.predict_folds([net], data, patch)
+    back = amd.preprocessing.resample_probabilities_for_export(probs, props)
+    ref_probs = tiler_ref.predict_3d_tiled(tiler_ref.make_net_fn(sd, unet_ref.default_cfg("batch")), ref_data, patch, 3)
+    ref_back = tiler_ref.export_resample_probs(ref_probs, ref_props)
+    assert tuple(back.shape[1:]) == props["size_after_cropping"] == tuple(ref_back.shape[1:])
+    assert np.abs(back.cpu().numpy() - ref_back).max() <= 5e-3
+    lo = [b[0] for b in props["crop_bbox"]]
+    seg = amd.ops.regions_to_labels(back, (1, 2, 3), lo, props["original_size_of_raw_data"]).cpu().numpy()
+    want = tiler_ref.paste_into_original(tiler_ref.regions_to_labels(ref_back.astype(np.float32)), ref_props["crop_bbox"], raw.shape[1:])
+    assert tiler_ref.brats_region_dice(seg, want)["mean"] >= 0.999
+    net.close()

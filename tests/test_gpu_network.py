@@ -118,7 +118,7 @@ def test_forward_128_model_a(amd, gpu):
     # tolerance, not only the direct kernels'
     import os
     if os.environ.get("MI355_WINOGRAD", "2") not in ("0", "1") and os.environ.get("MI355_CONV_IMPL") is None and os.environ.get("MI355_WINO3", "1") != "0":
-        assert "conv3_f32_wino3_kernel<0>" in kernels and "conv3_f32_wino3_kernel<1>" in kernels, sorted(kernels)
+        assert "conv3_f32_wino3_kernel<0, false>" in kernels and "conv3_f32_wino3_kernel<1, false>" in kernels, sorted(kernels)
 
 
 def _small_net(amd, norm="batch", seed=21):

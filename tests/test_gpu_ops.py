@@ -50,11 +50,11 @@ CONV_CASES = [
 
 #: which kernel an fp32 case is written for (asserted through mi355_last_conv_kernel)
 F32_EXPECT_KERNEL = {
-    (1, 64, 64, 64, 32, 64, 1, 1): "conv3_f32_wino3_kernel<0>",
-    (2, 16, 64, 128, 16, 32, 1, 1): "conv3_f32_wino3_kernel<0>",
-    (1, 24, 64, 256, 32, 32, 1, 1): "conv3_f32_wino3_kernel<0>",
-    (2, 32, 64, 64, 48, 64, 1, 1): "conv3_f32_wino3_kernel<0>",
-    (1, 64, 64, 72, 16, 32, 1, 1): "conv3_f32_wino3_kernel<0>",
+    (1, 64, 64, 64, 32, 64, 1, 1): "conv3_f32_wino3_kernel<0, false>",
+    (2, 16, 64, 128, 16, 32, 1, 1): "conv3_f32_wino3_kernel<0, false>",
+    (1, 24, 64, 256, 32, 32, 1, 1): "conv3_f32_wino3_kernel<0, false>",
+    (2, 32, 64, 64, 48, 64, 1, 1): "conv3_f32_wino3_kernel<0, false>",
+    (1, 64, 64, 72, 16, 32, 1, 1): "conv3_f32_wino3_kernel<0, false>",
     (3, 30, 37, 70, 48, 32, 1, 0): "conv3_f32_wino2_kernel<0>",
     (2, 30, 64, 128, 32, 32, 1, 0): "conv3_f32_wino2_kernel<0>",
     (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f32_s2dma_kernel<5>",
@@ -200,9 +200,9 @@ F16_EXPECT_KERNEL = {
     (8, 32, 32, 32, 64, 64, 1, 1): "conv3_f16_dma_kernel<false, false>",
     (2, 32, 64, 64, 48, 128, 1, 0): "conv3_f16_dma_kernel<false, false>",
     (4, 24, 40, 72, 16, 64, 1, 1): "conv3_f16_dma_kernel<false, false>",
-    (2, 64, 64, 64, 32, 128, 2, 1): "conv3_f16_s2dma_kernel<false>",
-    (2, 32, 32, 64, 64, 256, 2, 0): "conv3_f16_s2dma_kernel<false>",
-    (6, 24, 40, 48, 16, 128, 2, 1): "conv3_f16_s2dma_kernel<false>",
+    (2, 64, 64, 64, 32, 128, 2, 1): "conv3_f16_s2dma_kernel<false, 128>",
+    (2, 32, 32, 64, 64, 256, 2, 0): "conv3_f16_s2dma_kernel<false, 128>",
+    (6, 24, 40, 48, 16, 128, 2, 1): "conv3_f16_s2dma_kernel<false, 128>",
     (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f16_s2dma_kernel<false, 64>",
     (8, 8, 8, 8, 320, 320, 1, 1): "conv3_f16_mfma_kernel<1, 2, 2> split-K",
 }
@@ -252,11 +252,11 @@ SUMS_CASES = [
 SUMS_EXPECT_KERNEL = {
     (8, 32, 32, 32, 64, 64, 1, 0, "f16"): "conv3_f16_dma_kernel<true, false>",
     (4, 24, 40, 72, 16, 64, 1, 1, "f16"): "conv3_f16_dma_kernel<true, false>",
-    (2, 64, 64, 64, 32, 128, 2, 0, "f16"): "conv3_f16_s2dma_kernel<true>",
+    (2, 64, 64, 64, 32, 128, 2, 0, "f16"): "conv3_f16_s2dma_kernel<true, 128>",
     (2, 64, 64, 64, 32, 64, 2, 0, "f16"): "conv3_f16_s2dma_kernel<true, 64>",
-    (8, 32, 32, 32, 32, 32, 1, 0, "f32"): "conv3_f32_wino3_kernel<2>",
+    (8, 32, 32, 32, 32, 32, 1, 0, "f32"): "conv3_f32_wino3_kernel<2, false>",
     (8, 30, 32, 32, 32, 32, 1, 0, "f32"): "conv3_f32_wino2_kernel<2>",
-    (2, 32, 64, 64, 48, 64, 1, 1, "f32"): "conv3_f32_wino3_kernel<2>",
+    (2, 32, 64, 64, 48, 64, 1, 1, "f32"): "conv3_f32_wino3_kernel<2, false>",
     (2, 64, 64, 128, 32, 64, 2, 0, "f32"): "conv3_f32_s2dma_kernel<5>",
 }
 

@@ -111,3 +111,35 @@ def test_dice_formulas():
     d = tiler_ref.brats_region_dice(a, b)
     assert abs(d["WT"] - 2 * 3 / (4 + 3)) < 1e-6 and abs(d["ET"] - 2 * 1 / (2 + 2)) < 1e-6
     assert tiler_ref.brats_region_dice(a, a)["mean"] == pytest.approx(1.0)
+
+
+def test_resampling_restatement_decisions_and_identities():
+    """Row P step 4 / row E resampling (round 4; PARITY UNPINNED: nnU-Net v1 + skimage absent, restated on scipy).  The decision
+    table of resample_patient and the properties any faithful restatement has: identity at equal shape, exactness on linear
+    ramps for order 1, constants preserved and range clipped for order 3, the separate-z mode equal to per-slice 2-D resizes
+    followed by a nearest pick along z."""
+    T = tiler_ref
+    ns, sep, axis = T.resample_plan((60, 100, 100), (5.0, 1.0, 1.0), (1.0, 1.0, 1.0))
+    assert ns == (300, 100, 100) and sep and list(axis) == [0]
+    assert T.resample_plan((78, 120, 120), (2.0, 2.0, 2.0), (1.0, 1.0, 1.0))[:2] == ((156, 240, 240), False)
+    assert T.resample_plan((30, 120, 100), (1.25, 1.25, 0.24), (1.0, 1.0, 1.0))[1] is False          # two low-resolution axes
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal((2, 9, 11, 10)).astype(np.float32)
+    assert T.resample_data_or_seg(x, (9, 11, 10), False, None, 3, False) is x
+    ramp = (np.arange(10, dtype=np.float32)[None, None, None, :] * 2.0 + 1.0) * np.ones((1, 4, 5, 1), np.float32)
+    up = T.resample_data_or_seg(ramp, (4, 5, 20), False, None, 1, False)
+    inner = up[0, 0, 0, 1:-1]                                                                          # edge samples replicate
+    assert np.allclose(np.diff(inner), 1.0, atol=1e-5)
+    const = np.full((1, 6, 7, 8), 3.25, np.float32)
+    assert np.allclose(T.resample_data_or_seg(const, (9, 5, 12), False, None, 3, False), 3.25, atol=1e-6)
+    y = T.resample_data_or_seg(x, (13, 17, 7), False, None, 3, False)
+    for c in range(2):
+        assert y[c].min() >= x[c].min() - 1e-6 and y[c].max() <= x[c].max() + 1e-6                    # skimage clips to the input's range
+    sep = T.resample_data_or_seg(x, (18, 16, 7), False, np.array([0]), 3, True, order_z=0)
+    per_slice = np.stack([T.skimage_resize(x[0, k], (16, 7), 3) for k in range(9)], 0)
+    pick = np.floor((np.arange(18) + 0.5) * 9 / 18 - 0.5 + 0.5).clip(0, 8).astype(int)
+    assert np.allclose(sep[0], per_slice[pick], atol=1e-6)
+    seg = (rs.uniform(size=(1, 8, 9, 10)) > 0.5).astype(np.float32) - 1.0                             # the -1 / 0 pseudo-seg of crop_to_nonzero
+    out = T.resample_data_or_seg(seg, (12, 9, 15), True, None, 1, False)
+    lin = T.skimage_resize((seg[0] == 0).astype(float), (12, 9, 15), 1)
+    assert np.array_equal(out[0] >= 0, lin >= 0.5)
