@@ -612,13 +612,19 @@ def main(argv=None):
         if not args.no_reference_setting:
             ref = {dt: run_reference_setting(ctx, dt, data, props, steps_tbl, oracle) for dt in ("f16", "f32")}
             # the fp16 label volume against the fp32 label volume of the same run, all 155 x 240 x 240 voxels (a consistency check of
-            # the two paths of this library; the oracle's verdict on each is the fold-mean parity block above)
-            from oracle import tiler_ref
-            seg16, seg32 = ref["f16"].pop("_seg").cpu().numpy(), ref["f32"].pop("_seg").cpu().numpy()
-            d = tiler_ref.brats_region_dice(seg16, seg32)
+            # the two paths of this library through its own evaluator kernel; the oracle's verdict on each is the fold-mean parity
+            # block above).  Raw nnU-Net labels: WT = {1, 2, 3}, TC = {2, 3}, ET = {3}.
+            from brats_amd import evaluate
+            seg16, seg32 = ref["f16"].pop("_seg"), ref["f32"].pop("_seg")
+            cm = evaluate.confusion(seg16, seg32, 5).astype(np.float64)   # rows = fp16 label, columns = fp32 label
+            dices = []
+            for members in ((1, 2, 3), (2, 3), (3,)):
+                m = list(members)
+                tp = cm[np.ix_(m, m)].sum()
+                dices.append((2 * tp + 1e-8) / (cm[m, :].sum() + cm[:, m].sum() + 1e-8))
             ref["f16"]["consistency_vs_f32_labels"] = dict(sample="ensembled label volume of the timed case, fp16 path vs fp32 path of this run, all voxels",
-                                                            labels_differ=int((seg16 != seg32).sum()), voxels=int(seg16.size),
-                                                            dice_wt_tc_et_mean=round(d["mean"], 6))
+                                                            labels_differ=int(cm.sum() - np.trace(cm)), voxels=int(cm.sum()),
+                                                            dice_wt_tc_et_mean=round(float(np.mean(dices)), 6))
             secondary["reference_setting"] = ref
 
     if ctx.rank != 0:
