@@ -139,24 +139,41 @@ def test_dropin_missing_models_exit_code(amd, gpu, tmp_path):
     assert res.returncode == 1 and "[ERROR] Model not found" in res.stdout
 
 
-def test_dropin_refuses_a_grid_the_plans_would_resample(amd, gpu, tmp_path):
-    """a 2 mm input (e.g. an api.py upload) must not be segmented silently on the wrong grid.  The reference's
-    trainer.preprocess_patient would resample it to the plans' 1 mm spacing; resampling is not built, so the drop-in
-    fails loudly (non-zero exit -> run_full_pipeline.py:187-188 raises) instead of writing wrong labels / volumes."""
+def test_dropin_resamples_a_grid_that_is_not_the_plans(amd, gpu, tmp_path):
+    """A 2 mm input (e.g. an api.py upload) must not be segmented on the wrong grid.  Until round 3 the drop-in refused it; since
+    round 4 it does what the reference's trainer.preprocess_patient / save_segmentation_nifti_from_softmax do (driver :89,
+    :131-138): resample to the plans' 1 mm spacing (data order 3, inside mask order 1), predict, resample the probabilities back
+    with order 1, and write labels on the INPUT's grid.  Checked against the oracle's restatement of those steps (PARITY UNPINNED
+    like the rest of tiler_ref: nnU-Net v1 / skimage absent)."""
     patch = (32, 32, 32)
     results = tmp_path / "nnUNet_results"
     base = results / "3d_fullres" / "Task500_BraTS2021"
     plans = amd.checkpoint.default_brats_plans(patch)
+    sds = {}
     for name, preset, seed in ((amd.driver.MODEL1, "A", 40), (amd.driver.MODEL2, "B", 50)):
-        amd.checkpoint.save_model_folder(base / name, name.split("__")[0], [amd.synthetic.make_model(preset, seed=seed, num_pool=2, max_feat=64)[0]], plans)
+        sds[name] = amd.synthetic.make_model(preset, seed=seed, num_pool=2, max_feat=64)[0]
+        amd.checkpoint.save_model_folder(base / name, name.split("__")[0], [sds[name]], plans)
     case_dir = tmp_path / "case2mm"
     case_dir.mkdir()
-    _write_case(amd, case_dir, "BraTS-GLI-00009-000", (40, 56, 48), seed=79, zooms=(2.0, 2.0, 2.0))
+    raw = _write_case(amd, case_dir, "BraTS-GLI-00009-000", (24, 32, 28), seed=79, zooms=(2.0, 2.0, 2.0))
     res = subprocess.run([sys.executable, os.path.join(ROOT, "run_brats2021_inference_singlethread.py"), "--input", str(case_dir),
                           "--output", str(tmp_path / "out"), "--results_folder", str(results), "--folds", "0"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert res.returncode != 0 and "resampling is not implemented" in (res.stdout + res.stderr)
-    assert not (tmp_path / "out" / "BraTS-GLI-00009-000.nii.gz").exists()
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    img = amd.nifti.load(tmp_path / "out" / "BraTS-GLI-00009-000.nii.gz")
+    like = amd.nifti.load(case_dir / "BraTS-GLI-00009-000_t1.nii.gz")
+    assert img.data.shape == like.data.shape and img.zooms == like.zooms and set(np.unique(img.data)) <= {0, 1, 2, 3}
+    # the oracle's restatement: crop, resample to 1 mm, z-score, sliding window + TTA per member, probabilities back with order 1
+    data, props = tiler_ref.preprocess_case_resampled(raw, (2.0, 2.0, 2.0), (1.0, 1.0, 1.0))
+    assert props["size_after_resampling"] != props["size_after_cropping"]
+    segs = []
+    for name, cfg in ((amd.driver.MODEL1, unet_ref.default_cfg("batch")), (amd.driver.MODEL2, unet_ref.default_cfg("group", 16))):
+        probs = tiler_ref.predict_3d_tiled(tiler_ref.make_net_fn(sds[name], cfg), data, patch, 3)
+        back = tiler_ref.export_resample_probs(probs, props)
+        segs.append(tiler_ref.paste_into_original(tiler_ref.regions_to_labels(back.astype(np.float32)), props["crop_bbox"], raw.shape[1:]))
+    want = driver_ref.label_ensemble(segs[0], segs[1])
+    d = tiler_ref.brats_region_dice(img.as_zyx(), want)
+    assert d["mean"] >= 0.999, d
 
 
 def test_nnunet_predict_cli_save_npz_and_probability_ensemble(amd, gpu, tmp_path):
