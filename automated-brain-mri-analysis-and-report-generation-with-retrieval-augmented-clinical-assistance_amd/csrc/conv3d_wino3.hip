@@ -59,15 +59,21 @@ struct Wino3Args {
 #ifdef MI355_W3_STAMPS
 // Diagnostic build only (tools/wino3_probe.hip): cycle sums per phase, wave 0 of every workgroup.
 // Slots: 0 chunk prologue, 1 step loop, 2 chunk drain + barrier, 3 epilogue phase 1 (in-wave output transform), 4 whole epilogue,
-// 5 kernel, 6 chunks, 7 tiles, 9 accumulator reset, 10 whole chunk body (steps 0-3 + barrier).
+// 5 kernel, 6 chunks, 7 tiles, 9 accumulator reset, 10 whole chunk body (steps 0-3 + barrier), 11-14 steps 0-3 (MFMA loop only).
 __device__ unsigned long long w3_stamps[1024 * 16];
 #define W3_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
-#define W3_ACC(slot, a, b) do { if (threadIdx.x == 0) w3_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] += (b) - (a); } while (0)
-#define W3_CNT(slot) do { if (threadIdx.x == 0) w3_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] += 1; } while (0)
+// (sums live in scalar registers and are written once at the end: a read-modify-write in global memory per stamp put its own
+// vmcnt waits into the phase that followed it)
+#define W3_DECL unsigned long long w3_loc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define W3_ACC(slot, a, b) w3_loc[slot] += (b) - (a)
+#define W3_CNT(slot) w3_loc[slot] += 1
+#define W3_FLUSH do { if (threadIdx.x == 0) for (int s_ = 0; s_ < 16; ++s_) w3_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + s_] += w3_loc[s_]; } while (0)
 #else
 #define W3_T(var)
+#define W3_DECL
 #define W3_ACC(slot, a, b)
 #define W3_CNT(slot)
+#define W3_FLUSH
 #endif
 #ifndef MI355_W3_PIN
 #define MI355_W3_PIN 1   // epilogue phase 1: the accumulator reads are pinned every MI355_W3_PIN register pairs (see there)
@@ -133,7 +139,13 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     // (the hand-counted waits below need the same number of vector-memory operations in flight in all four waves): group 0 = range
     // w, group 1 = range w + 4 (four quads each, issued back to back: they share their 128-B lines), group 2 = two quads of range
     // 8 (waves 0, 1) or 9 (waves 2, 3).
-    unsigned dma_pk[3];
+    // Per lane and group, fixed for the whole kernel: the brick voxel (rz, ry, rx) as three one-hot fields (bit rz, bit 6 + ry,
+    // bit 16 + rx; bit 31 = padding slot beyond the 600 voxels) and its byte offset from the brick's corner in either input tensor.
+    // Per DMA stream position (tile, chunk), scalar: the corner's address and the same three fields with the planes / rows /
+    // columns that fall outside the volume set.  A piece is inside iff (need & notok) == 0: two vector instructions instead of
+    // unpacking and three range checks, and the scalar part is computed once per chunk, spread over the MFMA gaps of step 1
+    // (round 4: the stamps put 2 300 of a chunk's 12 250 cycles on the three gaps that held the DMA address arithmetic).
+    unsigned dma_need[3], dma_off0[3], dma_off1[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int v = (k < 2 ? wave + 4 * k : 8 + (wave >> 1)) * 64 + lane;
@@ -142,39 +154,46 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         const int rz = vv / 100, rem = vv - rz * 100;
         const int ry = rem / 10, r2 = rem - ry * 10;
         const int par = r2 / 5, xh = r2 - par * 5;
-        dma_pk[k] = (unsigned)(rz | (ry << 4) | ((2 * xh + par) << 8) | (pad << 16));
-    }
-    auto dma_group = [&](const TileCoord &tc, int ch, auto kc, float *buf) {
-        constexpr int k = decltype(kc)::value;
-        const int rng = k < 2 ? wave + 4 * k : 8 + (wave >> 1);  // scalar
+        const int rx = 2 * xh + par;
         const int q0 = k < 2 ? 0 : 2 * (wave & 1);
-        const int cglob = ch * 16;
-        const float *src; int Csrc, coff;
-        if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
-        else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
-        src += ((((size_t)tc.n * p.D + (tc.oz0 - 1)) * p.H + (tc.oy0 - 1)) * p.W + (tc.ox0 - 1)) * (long)Csrc + coff + 4 * q0;
-        unsigned pk = dma_pk[k];
-        asm volatile("" : "+v"(pk));  // unpack here, every time (hoisted out of the tile loop the fields get spilled)
-        const int rz = pk & 15, ry = (pk >> 4) & 15, rx = (pk >> 8) & 15, pad = pk >> 16;
-        const bool in_vol = !pad && ((unsigned)(tc.oz0 - 1 + rz) < (unsigned)p.D) && ((unsigned)(tc.oy0 - 1 + ry) < (unsigned)p.H) &&
-                            ((unsigned)(tc.ox0 - 1 + rx) < (unsigned)p.W);
-        const int voff = ((rz * p.H + ry) * p.W + rx) * Csrc;
-        if constexpr (INAFF) inmask = in_vol ? (inmask | (1u << k)) : (inmask & ~(1u << k));
-        const float *g = in_vol ? src + voff : p.zeros;
-        asm volatile("" : "+v"(g));  // one DMA per quad for every lane (a branchy select would break the vmcnt count)
-        float *dst = buf + rng * 64 * 4 + q0 * (W3_PS * 4);
+        dma_need[k] = pad ? 0x80000000u : ((1u << rz) | (1u << (6 + ry)) | (1u << (16 + rx)));
+        const unsigned vox = (unsigned)((rz * p.H + ry) * p.W + rx);
+        dma_off0[k] = (vox * (unsigned)p.C0 + 4u * q0) * 4u;
+        dma_off1[k] = (vox * (unsigned)p.C1 + 4u * q0) * 4u;
+    }
+    // DMA stream position and what is derived from it (all scalar)
+    TileCoord d_tc;
+    int d_tile, d_ch;
+    const char *d_src;   // address of the brick's corner voxel (may lie in front of the tensor), channel of the chunk's first quad
+    unsigned d_notok;    // one-hot fields of the planes / rows / columns outside the volume, | bit 31
+    bool d_sel1;         // the chunk's channels come from in1 (virtual concat)
+    // A group is issued in two halves (quads 0-1, then 2-3) in two consecutive MFMA gaps: four 1-KiB DMAs in one gap hold the
+    // wave's issue longer than one MFMA runs.
+    const float *dma_g = nullptr;
+    unsigned dma_m0 = 0;
+    auto dma_group = [&](auto kc, auto part_c, float *buf) {
+        constexpr int k = decltype(kc)::value, part = decltype(part_c)::value;
         // Inline asm, not __builtin_amdgcn_global_load_lds: hipcc tracks the builtin's LDS writes and, wherever it cannot prove that a
         // ds_read does not alias one in flight - at every loop back edge - it retires ALL vector memory operations (vmcnt(0)) in front
         // of the read; this pipeline keeps a DMA group in flight across the chunk loop's back edge by design (the barrier that
         // publishes the data is what orders it).  M0 = LDS byte address of lane 0's slot, one wait state between its write and its
         // use.  The instruction's immediate offset is added to the global AND the LDS address: quad Q's M0 is moved back by it.
-        const unsigned m0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)dst;
 #define W3_DMA(Q)                                                                                                         \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%2"                                \
-                 :: "s"(m0 + (unsigned)((Q) * (W3_PS * 16 - 16))), "v"(g), "n"((Q) * 16) : "memory", "m0")
-        W3_DMA(0);
-        W3_DMA(1);
-        if constexpr (k < 2) {
+                 :: "s"(dma_m0 + (unsigned)((Q) * (W3_PS * 16 - 16))), "v"(dma_g), "n"((Q) * 16) : "memory", "m0")
+        if constexpr (part == 0) {
+            const int rng = k < 2 ? wave + 4 * k : 8 + (wave >> 1);  // scalar
+            const int q0 = k < 2 ? 0 : 2 * (wave & 1);
+            const bool in_vol = (dma_need[k] & d_notok) == 0;
+            if constexpr (INAFF) inmask = in_vol ? (inmask | (1u << k)) : (inmask & ~(1u << k));
+            const unsigned off = d_sel1 ? dma_off1[k] : dma_off0[k];
+            dma_g = in_vol ? (const float *)(d_src + off) : p.zeros;
+            asm volatile("" : "+v"(dma_g));  // one DMA per quad for every lane (a branchy select would break the vmcnt count)
+            float *dst = buf + rng * 64 * 4 + q0 * (W3_PS * 4);
+            dma_m0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)dst;
+            W3_DMA(0);
+            W3_DMA(1);
+        } else if constexpr (k < 2) {
             W3_DMA(2);
             W3_DMA(3);
         }
@@ -300,22 +319,58 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     //                         the weights of that step, and DMA group 0 of chunk c + 2 into buffer c.
     // The brick DMA therefore runs as its own stream of (tile, chunk) positions, one chunk ahead of the MFMAs and across tile
     // boundaries; past the last chunk it re-stages the last one (nobody reads it), so the wait counts stay fixed.
+    W3_DECL;
     W3_T(t_kernel0);
     TileCoord cur = decode(tile);
-    TileCoord d_tc = cur;
-    int d_tile = tile, d_ch = 0;
-    auto d_advance = [&]() {
-        // branch-free (this runs between two MFMAs: a branch would cut the stream into basic blocks): all scalar selects
+    // The stream's next position, in eight scalar pieces (adv0 .. adv5) that the chunk loop deals over eight MFMA gaps of step 1,
+    // behind the issue of group 2: branch-free (a branch would cut the MFMA stream into basic blocks), ~10-15 scalar
+    // instructions each, which the scalar unit runs while the matrix pipe works on the MFMA in front of the gap.
+    int a_tt = 0, a_tx = 0, a_ty = 0, a_tz = 0, a_vox = 0, a_csrc = 0, a_coff = 0;
+    const float *a_ptr = nullptr;
+    auto adv0 = [&]() {   // (tile, chunk) <- next; past the last chunk of the last tile the position stays (re-staged, nobody reads it)
         const bool more_ch = d_ch + 1 < p.nchunks;
         const bool more_tiles = d_tile + nl < hi;
-        const int t2 = more_tiles ? d_tile + nl : d_tile;
-        const TileCoord c2 = decode(t2);
-        const bool wrap = !more_ch && more_tiles;
         d_ch = more_ch ? d_ch + 1 : (more_tiles ? 0 : d_ch);
-        d_tile = wrap ? t2 : d_tile;
-        d_tc.n = wrap ? c2.n : d_tc.n; d_tc.oz0 = wrap ? c2.oz0 : d_tc.oz0; d_tc.oy0 = wrap ? c2.oy0 : d_tc.oy0; d_tc.ox0 = wrap ? c2.ox0 : d_tc.ox0;
+        d_tile = (!more_ch && more_tiles) ? d_tile + nl : d_tile;
     };
-    static_for<0, 3>([&](auto kc) { dma_group(d_tc, d_ch, kc, lds); });
+    auto adv1 = [&]() {
+        d_tc.n = (int)fdiv((uint32_t)d_tile, p.div_tiles_per_n);
+        a_tt = d_tile - d_tc.n * (int)p.div_tiles_per_n.d;
+    };
+    int a_w = 0, a_bzy = 0, a_bxi = 0;
+    auto adv2a = [&]() {  // tile_from_id (common.h) in two halves
+        const int lb = p.order.lbx + p.order.lby + p.order.lbz;
+        a_w = a_tt & ((1 << lb) - 1);
+        const int blk = a_tt >> lb;
+        a_bzy = (int)fdiv((uint32_t)blk, p.order.div_nbx);
+        a_bxi = blk - a_bzy * (int)p.order.div_nbx.d;
+    };
+    auto adv2b = [&]() {
+        const int bzi = (int)fdiv((uint32_t)a_bzy, p.order.div_nby);
+        const int byi = a_bzy - bzi * (int)p.order.div_nby.d;
+        a_tx = (a_bxi << p.order.lbx) + (a_w & ((1 << p.order.lbx) - 1));
+        a_ty = (byi << p.order.lby) + ((a_w >> p.order.lbx) & ((1 << p.order.lby) - 1));
+        a_tz = (bzi << p.order.lbz) + (a_w >> (p.order.lbx + p.order.lby));
+    };
+    auto adv3 = [&]() {
+        d_tc.oz0 = a_tz << 2; d_tc.oy0 = a_ty << 3; d_tc.ox0 = a_tx << 3;
+        const int cglob = d_ch * 16;
+        d_sel1 = cglob >= p.C0;
+        a_ptr = d_sel1 ? p.in1 : p.in0;
+        a_csrc = d_sel1 ? p.C1 : p.C0;
+        a_coff = d_sel1 ? cglob - p.C0 : cglob;
+    };
+    auto adv4a = [&]() {  // (host: N * D * H * W < 2^30, wino3_fits)
+        a_vox = ((d_tc.n * p.D + (d_tc.oz0 - 1)) * p.H + (d_tc.oy0 - 1)) * p.W + (d_tc.ox0 - 1);
+    };
+    auto adv4b = [&]() {
+        d_notok = 0x80000000u | (d_tc.oz0 == 0 ? 1u : 0u) | (d_tc.oz0 + 4 == p.D ? 1u << 5 : 0u) | (d_tc.oy0 == 0 ? 1u << 6 : 0u) |
+                  (d_tc.oy0 + 8 == p.H ? 1u << 15 : 0u) | (d_tc.ox0 == 0 ? 1u << 16 : 0u) | (d_tc.ox0 + 8 == p.W ? 1u << 25 : 0u);
+    };
+    auto adv5 = [&]() { d_src = (const char *)a_ptr + ((long)a_vox * a_csrc + a_coff) * 4; };
+    d_tile = tile; d_ch = 0;
+    adv1(); adv2a(); adv2b(); adv3(); adv4a(); adv4b(); adv5();
+    static_for<0, 3>([&](auto kc) { dma_group(kc, I0{}, lds); dma_group(kc, I1{}, lds); });
     f32x4 uq[2][8];
     static_for<0, 8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -344,8 +399,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
 #pragma unroll
         for (int fy = 0; fy < 4; ++fy) x_op(Y, V[0], fy);
     }
-    d_advance();
-    dma_group(d_tc, d_ch, std::integral_constant<int, 0>{}, lds + W3_BUF);  // ("step 3 of chunk -1")
+    adv0(); adv1(); adv2a(); adv2b(); adv3(); adv4a(); adv4b(); adv5();
+    dma_group(I0{}, I0{}, lds + W3_BUF); dma_group(I0{}, I1{}, lds + W3_BUF);  // ("step 3 of chunk -1")
     {   // (the first tile's first step has no weight wait of its own: retire uq[0] here, behind the DMA group - once per kernel)
         auto &u0 = uq[0];
         W3_UWAIT(u0, 0);
@@ -363,6 +418,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         const TileCoord nxt_tile = ntile < hi ? decode(ntile) : cur;
         W3_T(t_t1);
         W3_ACC(9, t_t0, t_t1);
+        // (Tried in round 4: a second copy of the chunk body for chunk 0 whose first MFMAs take the constant 0 as C, which saves the
+        // 256 v_accvgpr_write above - 1 100 cycles of the pipe the f32 MFMAs run on, 3.5 % of a 32 -> 32 tile.  The build with two
+        // bodies ends in a memory access fault on every shape although its ISA reads correctly; not found, reverted.)
         for (int ch = 0; ch < p.nchunks; ++ch) {
             const bool last_ch = ch == p.nchunks - 1;
             const float *bufc = lds + buf * W3_BUF;
@@ -385,6 +443,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                 const float *wn = (st + 1 < STEPS) ? wch + (size_t)(st + 1) * (4 * 2048) : wnx;
                 const float *rb = (st + 1 < STEPS) ? bufc : bufn;   // brick the next quad is read from
                 constexpr int rq = (st + 1) & 3;
+                W3_T(t_s0);
                 static_for<0, 32>([&](auto i_c) {
                     constexpr int i = decltype(i_c)::value;
                     constexpr int f = i & 15, j = i >> 4;
@@ -426,13 +485,26 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                         if constexpr (i == 28) aff_compute(aff);
                         if constexpr (i == 29) aff_write(bufn, I2{}, I0{}, aff);
                     }
-                    if constexpr ((MI355_W3_ABL & 4) == 0 && i == 20) {
-                        if constexpr (st == 0) dma_group(d_tc, d_ch, std::integral_constant<int, 1>{}, bufn);
-                        if constexpr (st == 1) { dma_group(d_tc, d_ch, std::integral_constant<int, 2>{}, bufn); t_n = d_tc.n; t_ch = d_ch; d_advance(); }
-                        if constexpr (st == 3) dma_group(d_tc, d_ch, std::integral_constant<int, 0>{}, const_cast<float *>(bufc));
+                    if constexpr ((MI355_W3_ABL & 4) == 0 && (i == 20 || i == 21)) {
+                        typedef std::integral_constant<int, i - 20> Part;
+                        if constexpr (st == 0) dma_group(I1{}, Part{}, bufn);
+                        if constexpr (st == 1 && i == 20) { dma_group(I2{}, I0{}, bufn); t_n = d_tc.n; t_ch = d_ch; }
+                        if constexpr (st == 3) dma_group(I0{}, Part{}, const_cast<float *>(bufc));
+                    }
+                    if constexpr ((MI355_W3_ABL & 4) == 0 && st == 1) {  // the stream moves on: one scalar piece per gap
+                        if constexpr (i == 21) adv0();
+                        if constexpr (i == 22) adv1();
+                        if constexpr (i == 23) adv2a();
+                        if constexpr (i == 24) adv2b();
+                        if constexpr (i == 25) adv3();
+                        if constexpr (i == 26) adv4a();
+                        if constexpr (i == 27) adv4b();
+                        if constexpr (i == 28) adv5();
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                W3_T(t_s1);
+                W3_ACC(11 + st, t_s0, t_s1);
                 if constexpr (st == 2) {
                     W3_T(t_c2);
                     W3_ACC(1, t_c1, t_c2);
@@ -610,6 +682,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     }
     W3_T(t_kernel1);
     W3_ACC(5, t_kernel0, t_kernel1);
+    W3_FLUSH;
 #undef W3_ULOAD
 #undef W3_UWAIT
 }
@@ -684,6 +757,7 @@ static bool wino3_fits(const ConvWeights &w, const ConvCall &c) {
     const long tiles = (long)(c.Wi / 8) * (c.Hi / 8) * (c.Di / 4) * c.N;
     if (tiles * (w.cout / 32) < 1024 || tiles >= (1l << 30)) return false;
     if ((long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) >= (1l << 31)) return false;  // the per-lane part of a DMA address fits 32 bits
+    if ((long)c.N * c.Di * c.Hi * c.Wi >= (1l << 30)) return false;  // the brick corner's voxel index is a 32-bit scalar (adv4)
     return true;
 }
 
