@@ -585,15 +585,25 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
             // EPI == 1: logit[c] = sum_cout w[c][cout] * act(y[cout] + b[cout]) + hb[c] (generic_UNet.py:389-391, 1x1x1, no bias in the
             // reference's head).  A lane holds four couts of its voxel and the other 28 sit in the seven lanes beside it: four fmas per
             // class, then three DPP additions across the 8-lane group; lane `piece` = c stores class c.
+            // Round 4 (SQ pass: 7.6 VALU per MFMA, pipe 0.53 busy on this instantiation): the store address is a scalar base per output
+            // row + ONE tile-invariant lane offset (was: a 64-bit index product per row and lane), the class a lane stores is
+            // picked with v_cndmask from totals that are computed unconditionally (hipcc had sunk them into 35 branches).
             constexpr int KMAX = 4;
             f32x4 hq[KMAX];
             float hb = 0.f;
-            const int64_t Vo = (int64_t)p.D * p.H * p.W;
+            const unsigned Vo = (unsigned)(p.D * p.H * p.W);  // (host: head_ncls * D * H * W * 4 < 2^32)
+            unsigned lane_h = 0;
+            int pc = 0;
+            float *hrow0 = nullptr;
             if constexpr (EPI == 1) {
 #pragma unroll
                 for (int c = 0; c < KMAX; ++c)
                     hq[c] = c < p.head_ncls ? *(const f32x4 *)(p.head_w + c * p.Cout + co0 + piece * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-                hb = piece < p.head_ncls ? p.head_b[piece] : 0.f;
+                pc = piece < p.head_ncls ? piece : 0;
+                hb = p.head_b[pc];
+                lane_h = (unsigned)pc * Vo + (unsigned)((2 * (srow >> 2)) * p.W + 2 * (srow & 3));
+                // voxel (oz0, oy0 + oy, ox0 + ox) of class 0 of this sample: wave-uniform
+                hrow0 = p.head_out + (size_t)cur.n * p.head_ncls * Vo + ((size_t)cur.oz0 * p.H + cur.oy0 + oy) * p.W + cur.ox0 + ox;
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -636,10 +646,14 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                             v += dpp_perm<0x141>(v);  // row_half_mirror: the other quad of the 8-lane group
                             tot[c] = v;
                         }
-                        const float mine = piece == 0 ? tot[0] : piece == 1 ? tot[1] : piece == 2 ? tot[2] : tot[3];
-                        const int vz = cur.oz0 + 2 * (t >> 1) + oz, vy = cur.oy0 + oy + 4 * (t & 1) + 2 * (srow >> 2);
-                        if (piece < p.head_ncls)
-                            p.head_out[((int64_t)cur.n * p.head_ncls + piece) * Vo + ((int64_t)vz * p.H + vy) * p.W + vx] = mine + hb;
+                        asm volatile("" : "+v"(tot[0]), "+v"(tot[1]), "+v"(tot[2]), "+v"(tot[3]));  // (no sinking into the selects)
+                        float mine = tot[0];   // (lanes beyond the last class repeat lane 0's store: same address, same value - no exec mask, no branch)
+                        mine = pc == 1 ? tot[1] : mine;
+                        mine = pc == 2 ? tot[2] : mine;
+                        mine = pc == 3 ? tot[3] : mine;
+                        // row (z = oz0 + 2 (t >> 1) + oz, y = oy0 + oy + 4 (t & 1) [+ 2 (srow >> 2): in lane_h])
+                        float *hrow = hrow0 + (size_t)((2 * (t >> 1) + oz) * p.H + 4 * (t & 1)) * p.W;
+                        hrow[lane_h] = mine + hb;
                     } else if constexpr ((MI355_W3_ABL & 32) != 0) asm volatile("" :: "v"(val));
                     else {
                         float *gp = rowp + (size_t)oz * p.H * row_elems + lane_off;
@@ -752,6 +766,7 @@ bool conv3d_wino3_enabled() { return wino3_mode() != 0; }
 static bool wino3_fits(const ConvWeights &w, const ConvCall &c) {
     if (!wino3_mode() || !w.wp3_dev || w.stride != 1) return false;
     if (c.head_out && (w.cout != 32 || c.stats || c.head_ncls < 1 || c.head_ncls > 4 || !c.head_w || !c.head_b)) return false;
+    if (c.head_out && (long)c.head_ncls * c.Di * c.Hi * c.Wi >= (1l << 30)) return false;  // the head's lane offset is 32 bits
     if (c.in_scale && (c.C1 != 0 || !c.stats || c.head_out || !c.in_shift)) return false;
     if (c.Di % 4 || c.Hi % 8 || c.Wi % 8 || c.C0 % 16 || c.C1 % 16 || w.cout % 32 || (c.C0 + c.C1) != w.cin_pad) return false;
     const long tiles = (long)(c.Wi / 8) * (c.Hi / 8) * (c.Di / 4) * c.N;
