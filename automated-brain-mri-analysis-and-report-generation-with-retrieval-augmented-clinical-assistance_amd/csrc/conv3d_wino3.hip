@@ -406,6 +406,18 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         W3_UWAIT(u0, 0);
     }
 
+    // Kernel invariants of the epilogue's phase 2 (lane = 4 couts `piece` of a voxel): bias, and for the fused head its weights and
+    // bias.  Loaded once: as loads inside phase 2 their L2 round trip was exposed once per tile (vmcnt(0) in front of the first
+    // use, nothing to hide it behind).
+    const f32x4 bias_k = *(const f32x4 *)(p.bias + (int)blockIdx.y * 32 + (lane & 7) * 4);
+    f32x4 hq_k[4] = {};
+    float hb_k = 0.f;
+    if constexpr (EPI == 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            hq_k[c] = c < p.head_ncls ? *(const f32x4 *)(p.head_w + c * p.Cout + (int)blockIdx.y * 32 + (lane & 7) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        hb_k = p.head_b[(lane & 7) < p.head_ncls ? (lane & 7) : 0];
+    }
     int buf = 0;
     for (; tile < hi; tile += nl) {
         W3_T(t_t0);
@@ -571,7 +583,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
             const int srow = lane_e >> 3, piece = lane_e & 7;
             const float *rd = stage + wave * W3_IMG + srow * W3_PITCH + piece * 4;
             const int co0 = (int)blockIdx.y * 32;
-            const f32x4 bias = *(const f32x4 *)(p.bias + co0 + piece * 4);
+            f32x4 bias = bias_k;
+            asm volatile("" : "+v"(bias));  // (a copy per tile: the register pairs below are formed from it)
             const f32x2 b01 = {bias[0], bias[1]}, b23 = {bias[2], bias[3]};
             float slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.act == ACT_LRELU ? p.slope : 1.0f)));
             asm volatile("" : "+s"(slope));
@@ -597,10 +610,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
             float *hrow0 = nullptr;
             if constexpr (EPI == 1) {
 #pragma unroll
-                for (int c = 0; c < KMAX; ++c)
-                    hq[c] = c < p.head_ncls ? *(const f32x4 *)(p.head_w + c * p.Cout + co0 + piece * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < KMAX; ++c) hq[c] = hq_k[c];
                 pc = piece < p.head_ncls ? piece : 0;
-                hb = p.head_b[pc];
+                hb = hb_k;
                 lane_h = (unsigned)pc * Vo + (unsigned)((2 * (srow >> 2)) * p.W + 2 * (srow & 3));
                 // voxel (oz0, oy0 + oy, ox0 + ox) of class 0 of this sample: wave-uniform
                 hrow0 = p.head_out + (size_t)cur.n * p.head_ncls * Vo + ((size_t)cur.oz0 * p.H + cur.oy0 + oy) * p.W + cur.ox0 + ox;
