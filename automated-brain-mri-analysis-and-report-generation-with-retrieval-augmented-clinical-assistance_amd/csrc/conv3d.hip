@@ -1430,14 +1430,16 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
     };
     // weight DMA: dz plane `dz` of chunk `ch` = 18 KiB contiguous in the pack; KiB i goes to wave i & 3
     const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (27 * 2 * 256);
-    auto dma_weights = [&](int ch, int dz, float *slot) {
+    auto dma_weights = [&](int ch, int dz, float *slot, int i_lo = 0, int i_hi = 5) {
         const float *wsrc = wblk + ((size_t)ch * 27 + dz * 9) * (2 * 256) + lane * 4;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const int kib = wave + 4 * i;
-            if (kib < 18)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + kib * 256),
-                                                 (__attribute__((address_space(3))) void *)(slot + kib * 256), 16, 0, 0);
+            if (i < i_lo || i >= i_hi) continue;  // (compile-time at the call sites)
+            // (no branch: KiB 18 and 19 do not exist - waves 2 and 3 fetch KiB 16 and 17 a second time in the last round,
+            //  the same bytes into the same slot as waves 0 and 1)
+            const int kib = wave + 4 * i < 18 ? wave + 4 * i : wave + 4 * i - 2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + kib * 256),
+                                             (__attribute__((address_space(3))) void *)(slot + kib * 256), 16, 0, 0);
         }
     };
 
@@ -1464,38 +1466,54 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_s2dma_kernel(Wino2Args pa) {
         for (int ch = 0; ch < p.nchunks; ++ch) {
             const bool last_ch = ch == p.nchunks - 1;
             const bool have_next = !last_ch || ntile < hi;
-            const TileCoord nxt = last_ch ? nxt_tile : cur;
-            const int nch = last_ch ? 0 : ch + 1;
+            // (without a next chunk the fetches re-stage the current one into the idle buffers: no branch in the MFMA stream)
+            const TileCoord nxt = last_ch ? nxt_tile : cur;   // (nxt_tile = cur past the last tile)
+            const int nch = have_next ? (last_ch ? 0 : ch + 1) : ch;
             const float *bufc = lds + buf * S2_BUF_FLOATS;
             float *bufn = lds + (buf ^ 1) * S2_BUF_FLOATS;
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz) {
-                // fetches of the step: the next weight plane and a third of the next chunk's brick
-                if (dz < 2) dma_weights(ch, dz + 1, wring + (wslot ^ 1) * S2_WSLOT_FLOATS);
-                else if (have_next) dma_weights(nch, 0, wring + (wslot ^ 1) * S2_WSLOT_FLOATS);
-                if (have_next) {
-                    if (dz == 0) { dma_brick(nxt, nch, 0, bufn); dma_brick(nxt, nch, 1, bufn); dma_brick(nxt, nch, 2, bufn); }
-                    else if (dz == 1) { dma_brick(nxt, nch, 3, bufn); dma_brick(nxt, nch, 4, bufn); }
-                    else { dma_brick(nxt, nch, 5, bufn); dma_brick(nxt, nch, 6, bufn); }
-                }
+                // fetches of the step: the next weight plane and a third of the next chunk's brick - issued from inside the tap loop
+                // (round 4: in front of it, their ~11 DMAs and address arithmetic ran with the matrix pipe idle, once per step)
+                auto step_fetch = [&](int piece) {
+                    if (piece < 2) {  // the weight plane's 18 KiB: rounds 0-1, then 2-4
+                        const int lo = piece == 0 ? 0 : 2, hi = piece == 0 ? 2 : 5;
+                        if (dz < 2) dma_weights(ch, dz + 1, wring + (wslot ^ 1) * S2_WSLOT_FLOATS, lo, hi);
+                        else dma_weights(nch, 0, wring + (wslot ^ 1) * S2_WSLOT_FLOATS, lo, hi);
+                    } else {
+                        const int q = piece - 1;
+                        const int k = dz == 0 ? q - 1 : (dz == 1 ? 2 + q : 4 + q);   // dz 0: ranges 0 1 2, dz 1: 3 4, dz 2: 5 6
+                        if (q <= (dz == 0 ? 3 : 2)) dma_brick(nxt, nch, k, bufn);
+                    }
+                };
                 const float *wcur = wring + wslot * S2_WSLOT_FLOATS + lane * 4;
                 f32x4 a_cur, a_nxt, b_cur[2], b_nxt[2];
                 a_cur = *(const f32x4 *)(bufc + a_base + dz * IY * IX * 4);
                 b_cur[0] = *(const f32x4 *)(wcur);
                 b_cur[1] = *(const f32x4 *)(wcur + 256);
+                // The next tap's fragments are read BEHIND the first two MFMAs of this tap (round 4).  With an LDS-DMA in flight hipcc
+                // does not count LDS reads (every wait is lgkmcnt(0)): read at the top of the tap, as before, the three reads
+                // were waited for on the spot - their latency exposed nine times a step, which is what kept this kernel's matrix
+                // pipe at 0.72.  Now the wait comes in front of the NEXT tap's first MFMA, six MFMAs later.
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    if (t + 1 < 9) {
-                        const int dy = (t + 1) / 3, dx = (t + 1) - dy * 3;
-                        a_nxt = *(const f32x4 *)(bufc + a_base + ((dz * IY + dy) * IX + dx) * 4);
-                        b_nxt[0] = *(const f32x4 *)(wcur + (t + 1) * 512);
-                        b_nxt[1] = *(const f32x4 *)(wcur + (t + 1) * 512 + 256);
-                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int nf = 0; nf < 2; ++nf)
+                        for (int nf = 0; nf < 2; ++nf) {
                             acc[0][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nf][j], a_cur[j], acc[0][nf], 0, 0, 0);
+                            if (j == 0 && nf == 1) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (t + 1 < 9) {
+                                    const int dy = (t + 1) / 3, dx = (t + 1) - dy * 3;
+                                    a_nxt = *(const f32x4 *)(bufc + a_base + ((dz * IY + dy) * IX + dx) * 4);
+                                    b_nxt[0] = *(const f32x4 *)(wcur + (t + 1) * 512);
+                                    b_nxt[1] = *(const f32x4 *)(wcur + (t + 1) * 512 + 256);
+                                }
+                                if (t < 5) step_fetch(t);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
                     a_cur = a_nxt; b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier
