@@ -782,7 +782,11 @@ static bool wino3_fits(const ConvWeights &w, const ConvCall &c) {
     if (c.in_scale && (c.C1 != 0 || !c.stats || c.head_out || !c.in_shift)) return false;
     if (c.Di % 4 || c.Hi % 8 || c.Wi % 8 || c.C0 % 16 || c.C1 % 16 || w.cout % 32 || (c.C0 + c.C1) != w.cin_pad) return false;
     const long tiles = (long)(c.Wi / 8) * (c.Hi / 8) * (c.Di / 4) * c.N;
-    if (tiles * (w.cout / 32) < 1024 || tiles >= (1l << 30)) return false;
+    // Enough (tile, cout block) units to fill the chip - or, for the deep levels (8 x 8^3 x 320 channels: 160 units of 20 chunks
+    // each), enough chunks per unit that one tile per workgroup on 160 of the 256 CUs still beats the direct split-K kernel, which
+    // executes 27/8 of the multiplies at 0.57 of the pipe (round 4: 0.26 -> 0.11 ms per launch).
+    const long units = tiles * (w.cout / 32);
+    if ((units < 1024 && !(units >= 96 && w.cin_pad >= 128)) || tiles >= (1l << 30)) return false;
     if ((long)c.Di * c.Hi * c.Wi * (c.C0 > c.C1 ? c.C0 : c.C1) >= (1l << 31)) return false;  // the per-lane part of a DMA address fits 32 bits
     if ((long)c.N * c.Di * c.Hi * c.Wi >= (1l << 30)) return false;  // the brick corner's voxel index is a 32-bit scalar (adv4)
     return true;
