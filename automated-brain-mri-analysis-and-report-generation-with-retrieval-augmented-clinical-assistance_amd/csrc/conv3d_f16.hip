@@ -1404,7 +1404,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
         const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
         typedef DmaGeomH<2> GA;
         const size_t tab_bytes = c.in_scale ? (size_t)c.N * c.C0 * 4 : 0;  // fused input norm: fp16 scale + shift tables in LDS
-        if (dmak && tiles * gy >= 512 && tiles < (1l << 30) && b.Do % 8 == 0 && b.Ho % 8 == 0 && b.Wo % 8 == 0 &&
+        if (dmak && tiles * gy >= 256 && tiles < (1l << 30) && b.Do % 8 == 0 && b.Ho % 8 == 0 && b.Wo % 8 == 0 &&
             (long)10 * c.Hi * c.Wi < (1l << 24) && ((long)10 * c.Hi * c.Wi + 8l * c.Di * c.Hi * c.Wi) * 16 < (1l << 32) &&
             (!c.in_scale || (c.C1 == 0 && tab_bytes <= (size_t)GA::TAB_MAX_BYTES))) {
             void *zeros = nullptr;  // the zero page out-of-volume DMA pieces read

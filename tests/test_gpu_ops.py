@@ -190,6 +190,7 @@ F16_CONV_CASES = [
     (2, 4, 4, 4, 320, 320, 1, 1),    # bottleneck-sized launch
     (8, 32, 32, 32, 64, 64, 1, 1),   # Cout % 64 == 0, volume a whole number of 8^3 tiles, >= 512 tiles: the LDS-DMA kernel
     (2, 32, 64, 64, 48, 128, 1, 0),  # the same kernel: 3 chunks, two cout blocks, no activation
+    (8, 16, 16, 16, 256, 256, 1, 1), # the same kernel at the 16^3 level: 64 tiles x 4 cout blocks = one workgroup per CU, 16 chunks (round 4: threshold 512 -> 256 units)
     (4, 24, 40, 72, 16, 64, 1, 1),   # the same kernel: one chunk, odd tile counts (3 x 5 x 9 -> linear tile order), 540 tiles (not a multiple of 8: uneven XCD split)
     (2, 64, 64, 64, 32, 128, 2, 1),  # round 3: stride 2, Cout % 128 == 0, whole 4 x 4 x 8 output tiles -> conv3_f16_s2dma_kernel, 2 chunks
     (2, 32, 32, 64, 64, 256, 2, 0),  # the same kernel: two cout blocks of 128, 4 chunks, no activation
@@ -201,6 +202,7 @@ F16_EXPECT_KERNEL = {
     (8, 32, 32, 32, 64, 64, 1, 1): "conv3_f16_dma_kernel<false, false>",
     (2, 32, 64, 64, 48, 128, 1, 0): "conv3_f16_dma_kernel<false, false>",
     (4, 24, 40, 72, 16, 64, 1, 1): "conv3_f16_dma_kernel<false, false>",
+    (8, 16, 16, 16, 256, 256, 1, 1): "conv3_f16_dma_kernel<false, false>",
     (2, 64, 64, 64, 32, 128, 2, 1): "conv3_f16_s2dma_kernel<false, 128>",
     (2, 32, 32, 64, 64, 256, 2, 0): "conv3_f16_s2dma_kernel<false, 128>",
     (6, 24, 40, 48, 16, 128, 2, 1): "conv3_f16_s2dma_kernel<false, 128>",
