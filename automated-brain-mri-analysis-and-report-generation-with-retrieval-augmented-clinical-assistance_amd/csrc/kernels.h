@@ -106,7 +106,7 @@ int tconv_weights_upload(const float *w_host, int cin, int cout, TConvWeights *o
 void tconv_weights_free(TConvWeights *w);
 // in [N,D,H,W,Cin] -> out [N,2D,2H,2W,Cout]
 int tconv2_mfma_f32(const TConvWeights &w, const float *in, int N, int D, int H, int W, float *out,
-                    hipStream_t s);
+                    hipStream_t s, const char **kernel_name = nullptr);
 struct TConvWeightsH {
     int cin = 0, cout = 0;
     _Float16 *wp_dev = nullptr;

@@ -182,6 +182,101 @@ __global__ __launch_bounds__(256) void tconv2_f32_mfma_v2_kernel(const float *__
     }
 }
 
+// Version 3 (round 4; the fp16 kernel has had it since round 3): version 2 made persistent, with the wave's weights in registers.
+// A workgroup of version 2 re-reads its weight block (Cin x 1 KiB) from the L2 for every 128 voxels, waits for each fragment in
+// front of the MFMAs that use it, and has nothing to overlap its load - compute - store sequence with but the other
+// workgroups of its CU.  Here the two parities' fragments of a wave stay in 8 G = Cin registers (G = Cin / 8 = 8 or 16) and the
+// workgroup strides over the voxel tiles; per tile only the 128 x Cin input block comes through the L1.
+template <int G>
+__global__ __launch_bounds__(256, G <= 8 ? 2 : 1) void tconv2_f32_mfma_v3_kernel(const float *__restrict__ in,
+                                                                                const float *__restrict__ wp, float *out, int M,
+                                                                                int Cout, int D, int H, int W, FastDiv divW,
+                                                                                FastDiv divH, FastDiv divD) {
+    constexpr int Cin = G * 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nblk = Cout >> 5;
+    const int nb = (int)blockIdx.y;
+    constexpr int XPLANE = 128 * 4 + 4;  // floats (version 2's image: planar [16-B channel quad][voxel], 64 channels at a time)
+    __shared__ __attribute__((aligned(16))) float xs[16 * XPLANE];
+    __shared__ __attribute__((aligned(16))) float tr[4][32 * 32];
+    f32x4 wreg[2][G];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int g = 0; g < G; ++g) wreg[pp][g] = *(const f32x4 *)(wp + ((size_t)((wave * 2 + pp) * nblk + nb) * G + g) * 256 + lane * 4);
+    float *mytr = tr[wave];
+    const int Ho = 2 * H, Wo = 2 * W, Do = 2 * D;
+    const int ntiles = (M + 127) >> 7;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+        const int m0 = tile * 128;
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pp][mf][r] = 0.f;
+#pragma unroll
+        for (int c0 = 0; c0 < Cin; c0 += 64) {
+            if (c0 || tile != (int)blockIdx.x) __syncthreads();  // the previous image's fragment reads are done
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {  // 128 voxels x 16 channel quads, whole-line loads (16 lanes = the 256 B of a voxel)
+                const int i = k2 * 256 + tid, v = i >> 4, q = i & 15;
+                int vg = m0 + v;
+                if (vg >= M) vg = M - 1;
+                *(f32x4 *)(xs + q * XPLANE + v * 4) = *(const f32x4 *)(in + (size_t)vg * Cin + c0 + q * 4);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                f32x4 x[4];
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) x[mf] = *(const f32x4 *)(xs + (2 * g + half) * XPLANE + (mf * 32 + l31) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                        for (int mf = 0; mf < 4; ++mf)
+                            acc[pp][mf] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[pp][(c0 >> 3) + g][j], x[mf][j], acc[pp][mf], 0, 0, 0);
+            }
+        }
+        // epilogue: version 2's (4-KB LDS transpose per 32-voxel x 32-cout tile, whole-line stores)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int v = m0 + mf * 32 + l31;
+            const int vc = v < M ? v : M - 1;
+            const uint32_t q1 = fdiv((uint32_t)vc, divW);
+            const int x = vc - (int)q1 * W;
+            const uint32_t q2 = fdiv(q1, divH);
+            const int y = (int)q1 - (int)q2 * H;
+            const uint32_t n = fdiv(q2, divD);
+            const int z = (int)q2 - (int)n * D;
+            const long vox000 = v < M ? ((((long)n * Do + 2 * z) * Ho + 2 * y) * Wo + 2 * x) * Cout : -1;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int pos = wave * 2 + pp;
+                const int pa = pos >> 2, pb = (pos >> 1) & 1, pc = pos & 1;
+                const long padd = (((long)pa * Ho + pb) * Wo + pc) * Cout + nb * 32;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 val = {acc[pp][mf][4 * g4], acc[pp][mf][4 * g4 + 1], acc[pp][mf][4 * g4 + 2], acc[pp][mf][4 * g4 + 3]};
+                    *(f32x4 *)(mytr + l31 * 32 + (((2 * g4 + half) ^ (l31 & 7)) << 2)) = val;
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = it * 8 + (lane >> 3), c = lane & 7;
+                    const f32x4 val = *(const f32x4 *)(mytr + r * 32 + ((c ^ (r & 7)) << 2));
+                    const int lo = __shfl((int)(vox000 & 0xffffffff), r), hi = __shfl((int)(vox000 >> 32), r);
+                    const long vo = ((long)hi << 32) | (unsigned)lo;
+                    if (vo >= 0) *(f32x4 *)(out + (vo + padd) + c * 4) = val;
+                }
+            }
+        }
+    }
+}
+
 // pack: [pos = a*4+b*2+c][cout block][g][lane][j]; cout = nb*32 + (lane&31), cin = g*8 + (lane>>5)*4 + j
 int tconv_weights_upload(const float *w_host, int cin, int cout, TConvWeights *out) {
     MI355_REQUIRE(cin % 8 == 0 && cout % 32 == 0, "tconv %d->%d: need cin %% 8 == 0 and cout %% 32 == 0", cin, cout);
@@ -211,11 +306,30 @@ void tconv_weights_free(TConvWeights *w) {
 }
 
 int tconv2_mfma_f32(const TConvWeights &w, const float *in, int N, int D, int H, int W, float *out,
-                    hipStream_t s) {
+                    hipStream_t s, const char **kernel_name) {
     const long M = (long)N * D * H * W;
     MI355_REQUIRE(M > 0 && M < (1l << 30), "tconv: %ld voxels out of range", M);
     static int v1 = -1;
     if (v1 < 0) { const char *e = getenv("MI355_TCONV_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
+    static int v3 = -1;
+    if (v3 < 0) { const char *e = getenv("MI355_TCONV_V3"); v3 = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }
+    const long ntiles = (M + 127) / 128;
+    // (Cin = 128 - 128 weight registers, one workgroup per CU - measured slower than version 2: 3.4 against 3.0 ms for 128 -> 64 @ 8 x 32^3;
+    //  MI355_TCONV_V3=2 still takes it)
+    if (!v1 && v3 && (w.cin == 64 || (w.cin == 128 && v3 == 2)) && ntiles >= 1024) {
+        // persistent: the resident slots (two workgroups per CU at Cin = 64, one at 128: 128 weight registers) shared by the cout blocks
+        const int nblk = w.cout / 32;
+        long gx = (w.cin == 64 ? 512 : 256) / nblk;
+        if (gx < 8) gx = 8;
+        if (gx > ntiles) gx = ntiles;
+        dim3 grid3((unsigned)gx, nblk);
+        if (kernel_name) *kernel_name = w.cin == 64 ? "tconv2_f32_mfma_v3_kernel<8>" : "tconv2_f32_mfma_v3_kernel<16>";
+        if (w.cin == 64) hipLaunchKernelGGL(tconv2_f32_mfma_v3_kernel<8>, grid3, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cout, D, H, W, make_fastdiv(W), make_fastdiv(H), make_fastdiv(D));
+        else hipLaunchKernelGGL(tconv2_f32_mfma_v3_kernel<16>, grid3, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cout, D, H, W, make_fastdiv(W), make_fastdiv(H), make_fastdiv(D));
+        MI355_HIP(hipGetLastError());
+        return MI355_OK;
+    }
+    if (kernel_name) *kernel_name = v1 ? "tconv2_f32_mfma_kernel<2>" : "tconv2_f32_mfma_v2_kernel";
     if (!v1) {
         dim3 grid((unsigned)((M + 127) / 128), w.cout / 32);
         hipLaunchKernelGGL(tconv2_f32_mfma_v2_kernel, grid, dim3(256), 0, s, in, w.wp_dev, out, (int)M, w.cin, w.cout, D, H, W,

@@ -412,7 +412,7 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
                          es * (vin * tcin + 8.0 * vin * tcout + 8.0 * tcin * tcout));
             const char *tname = nullptr;
             if (f16) { MI355_TRY(tconv2_mfma_f16(net->tuh[u], (const _Float16 *)cur, N, Dl / 2, Hl / 2, Wl / 2, (_Float16 *)up, s, &tname)); ps.rename(tname); }
-            else MI355_TRY(tconv2_mfma_f32(net->tu[u], (const float *)cur, N, Dl / 2, Hl / 2, Wl / 2, (float *)up, s));
+            else { MI355_TRY(tconv2_mfma_f32(net->tu[u], (const float *)cur, N, Dl / 2, Hl / 2, Wl / 2, (float *)up, s, &tname)); ps.rename(tname); }
         }
         // concat order (upsampled, skip): generic_UNet.py:438 - never materialised
         const void *in0 = up, *in1 = skip[l];
@@ -907,8 +907,9 @@ extern "C" int mi355_tconv3d_ndhwc(const float *x_dev, int n, int d, int h, int 
     MI355_TRY(require_device());
     TConvWeights tw;
     MI355_TRY(tconv_weights_upload(weight_host, cin, cout, &tw));
-    int rc = tconv2_mfma_f32(tw, x_dev, n, d, h, w, y_dev, (hipStream_t)stream);
-    g_last_conv_kernel = "tconv2_f32_mfma_v2_kernel";
+    const char *tname = "tconv2_f32_mfma_v2_kernel";
+    int rc = tconv2_mfma_f32(tw, x_dev, n, d, h, w, y_dev, (hipStream_t)stream, &tname);
+    g_last_conv_kernel = tname;
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     tconv_weights_free(&tw);
     if (rc == MI355_OK && e != hipSuccess) { set_error("tconv kernel failed: %s", hipGetErrorString(e)); rc = MI355_ERR_HIP; }

@@ -1,5 +1,7 @@
 """-m gpu: single-kernel parity through the C ABI against torch-CPU fp32 (the reference's own
 backend, L0 in SURVEY.md section 1).  Tolerances are for fp32 summation-order differences only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -123,6 +125,24 @@ def test_tconv_matches_torch(amd, gpu, case):
     ref = F.conv_transpose3d(torch.from_numpy(x).permute(0, 4, 1, 2, 3), torch.from_numpy(wt), None, stride=2)
     ref = ref.permute(0, 2, 3, 4, 1).contiguous().numpy()
     y = amd.ops.tconv3d_ndhwc(torch.from_numpy(x).to(gpu), wt).cpu().numpy()
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", [(1, 33, 63, 65, 64, 32), (2, 32, 32, 64, 64, 32)])
+def test_tconv_f32_persistent_kernel_matches_torch(amd, gpu, case):
+    """Round 4: tconv2_f32_mfma_v3_kernel (persistent, the wave's weights in registers; Cin 64 and >= 1024 tiles of 128 input
+    voxels - the largest decoder level of the fp32 path; the Cin = 128 instantiation is behind MI355_TCONV_V3=2).  One case is ragged (33 x 63 x 65 = 135135 voxels: the clamped tail
+    tile and its store predicate); the kernel that ran is asserted."""
+    n, d, h, w, cin, cout = case
+    rs = np.random.RandomState(16)
+    x = _rand(rs, n, d, h, w, cin)
+    wt = (_rand(rs, cin, cout, 2, 2, 2) / np.sqrt(cin)).astype(np.float32)
+    ref = F.conv_transpose3d(torch.from_numpy(x).permute(0, 4, 1, 2, 3), torch.from_numpy(wt), None, stride=2)
+    ref = ref.permute(0, 2, 3, 4, 1).contiguous().numpy()
+    y = amd.ops.tconv3d_ndhwc(torch.from_numpy(x).to(gpu), wt).cpu().numpy()
+    if "MI355_TCONV_V3" not in os.environ and "MI355_TCONV_V1" not in os.environ:
+        assert amd.ops.last_conv_kernel().startswith("tconv2_f32_mfma_v3_kernel<"), amd.ops.last_conv_kernel()
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
