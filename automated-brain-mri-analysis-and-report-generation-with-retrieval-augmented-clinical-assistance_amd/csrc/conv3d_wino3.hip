@@ -258,41 +258,53 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
 
     // INAFF: the five piece PAIRS a lane fetched of a chunk - groups 0 and 1: quads (0, 1) and (2, 3) of its range, group 2: its two
     // quads of range 8 / 9 - are normalised in three phases each (read, compute, write), dealt over MFMA gaps by the caller.
-    struct AffPair { f32x4 r0, r1, s0, s1, t0, t1; };
+    struct AffPair { f32x4 r0, r1; };
     auto aff_slot = [&](float *b, auto gc, auto jc) -> float * {
         constexpr int g = decltype(gc)::value, j = decltype(jc)::value;
         const int rng = g < 2 ? wave + 4 * g : 8 + (wave >> 1);
         const int qa = g < 2 ? 2 * j : 2 * (wave & 1);
         return b + (qa * W3_PS + rng * 64) * 4 + lane * 4;
     };
-    auto aff_read = [&](float *b, int n, int ch, auto gc, auto jc, AffPair &a) {
-        constexpr int g = decltype(gc)::value, j = decltype(jc)::value;
-        const int qa = g < 2 ? 2 * j : 2 * (wave & 1);
+    // Scale / shift of the staged chunk's 16 channels (wave-uniform): eight 16-byte VECTOR loads per chunk with a scalar base and a zero
+    // lane offset, in inline asm, issued in step 0 in front of DMA group 1 - step 1's vmcnt(4) (everything but that group's four
+    // DMAs) retires them with the weights, so the hand-counted waits do not change; used in step 2.
+    // History: (1) plain global loads - hipcc made vector loads of them and, the asm statements around clobbering "memory", put
+    // vmcnt(0) in front of every use: +17 %; (2) scalar loads through the constant address space, four per piece pair in step 2 - a
+    // scalar load returns out of order, so its wait is lgkmcnt(0), which also waits for every LDS read in flight: five such stalls
+    // per chunk (stamps: step 2 3 580 cycles against 2 350 without the fused norm); (3) scalar loads once per chunk, copied to
+    // vector registers two gaps later - 32 more live scalar registers pushed the lane-spill registers into scratch, whose loads
+    // are vector memory operations: vmcnt(0) all over step 2, 5 930 cycles.
+    // (The table is written by norm_finalize, a previous launch.)
+    f32x4 aff_sc[4], aff_sh[4];          // [channel quad]
+    auto aff_table_load = [&](int n, int ch) {
+        auto uni = [](const float *x) {
+            const unsigned long long v = (unsigned long long)x;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return (const float *)(((unsigned long long)hi << 32) | lo);
+        };
+        const float *q = uni(p.in_scale + (size_t)n * p.C0 + ch * 16), *r = uni(p.in_shift + (size_t)n * p.C0 + ch * 16);
+        unsigned zoff = 0;
+        asm volatile("" : "+v"(zoff));
+#define W3_TLOAD(DST, SBASE, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(DST) : "v"(zoff), "s"(SBASE), "n"(IMM) : "memory")
+        W3_TLOAD(aff_sc[0], q, 0); W3_TLOAD(aff_sc[1], q, 16); W3_TLOAD(aff_sc[2], q, 32); W3_TLOAD(aff_sc[3], q, 48);
+        W3_TLOAD(aff_sh[0], r, 0); W3_TLOAD(aff_sh[1], r, 16); W3_TLOAD(aff_sh[2], r, 32); W3_TLOAD(aff_sh[3], r, 48);
+#undef W3_TLOAD
+    };
+    // ("redefined here": the compiler must not read or move the table registers in front of the wait that retires their loads)
+    auto aff_table_landed = [&]() {
+        asm volatile("" : "+v"(aff_sc[0]), "+v"(aff_sc[1]), "+v"(aff_sc[2]), "+v"(aff_sc[3]), "+v"(aff_sh[0]), "+v"(aff_sh[1]), "+v"(aff_sh[2]), "+v"(aff_sh[3]));
+    };
+    auto aff_read = [&](float *b, auto gc, auto jc, AffPair &a) {
         const float *s0 = aff_slot(b, gc, jc);
         a.r0 = *(const f32x4 *)s0;
         a.r1 = *(const f32x4 *)(s0 + W3_PS * 4);
-        // scale / shift of the two quads: wave-uniform addresses, read through the CONSTANT address space so that they are scalar
-        // loads (s_load_dwordx4 -> SGPRs, lgkmcnt).  As plain global loads hipcc made vector loads of them - the asm statements
-        // around clobber "memory", so it may not assume the table unchanged - and retired ALL vector memory operations
-        // (vmcnt(0): weights, brick DMAs) in front of every use: +17 % on these launches, more than the separate pass costs.
-        // (The table is written by norm_finalize, a previous launch: reading it through the scalar cache is safe.)
-        const size_t ci = (size_t)n * p.C0 + ch * 16 + 4 * qa;
-        typedef const __attribute__((address_space(4))) f32x4 cf32x4;
-        auto uni = [](const float *q) {
-            const unsigned long long v = (unsigned long long)q;
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-            return (cf32x4 *)(((unsigned long long)hi << 32) | lo);
-        };
-        cf32x4 *sp = uni(p.in_scale + ci), *tp = uni(p.in_shift + ci);
-        a.s0 = sp[0]; a.s1 = sp[1];
-        a.t0 = tp[0]; a.t1 = tp[1];
     };
-    auto aff_apply = [&](f32x4 &r, const f32x4 &sc, const f32x4 &sh) {
+    auto aff_apply1 = [&](f32x4 &r, const f32x4 &sc, const f32x4 &sh) {
         const f32x2 sl2 = {p.in_slope, p.in_slope};
         f32x2 a = {r[0], r[1]}, b = {r[2], r[3]}, ya, yb, za, zb;
         const f32x2 s01 = {sc[0], sc[1]}, s23 = {sc[2], sc[3]}, t01 = {sh[0], sh[1]}, t23 = {sh[2], sh[3]};
-        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(ya) : "v"(a), "s"(s01), "v"(t01));  // (one scalar source per instruction: the scale)
-        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(yb) : "v"(b), "s"(s23), "v"(t23));
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(ya) : "v"(a), "v"(s01), "v"(t01));
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(yb) : "v"(b), "v"(s23), "v"(t23));
         asm("v_pk_mul_f32 %0, %1, %2" : "=v"(za) : "v"(ya), "v"(sl2));
         asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zb) : "v"(yb), "v"(sl2));
         asm("v_max_f32 %0, %1, %2" : "=v"(r[0]) : "v"(ya[0]), "v"(za[0]));
@@ -300,7 +312,22 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         asm("v_max_f32 %0, %1, %2" : "=v"(r[2]) : "v"(yb[0]), "v"(zb[0]));
         asm("v_max_f32 %0, %1, %2" : "=v"(r[3]) : "v"(yb[1]), "v"(zb[1]));
     };
-    auto aff_compute = [&](AffPair &a) { aff_apply(a.r0, a.s0, a.t0); aff_apply(a.r1, a.s1, a.t1); };
+    // half 0 / 1 of a pair = its first / second quad: groups 0, 1 hold quads (2 j, 2 j + 1), group 2 quads (2 (wave & 1), + 1)
+    auto aff_apply = [&](auto gc, auto jc, auto hc, AffPair &a) {
+        constexpr int g = decltype(gc)::value, j = decltype(jc)::value, h = decltype(hc)::value;
+        f32x4 &r = h == 0 ? a.r0 : a.r1;
+        if constexpr (g < 2) aff_apply1(r, aff_sc[2 * j + h], aff_sh[2 * j + h]);
+        else {
+            // (wave-uniform: four v_cndmask per operand.  The operands are laundered first: hipcc turned `w1 ? t[2 + h] : t[h]` into a
+            //  dynamically indexed read of a PRIVATE copy of the table - scratch loads, i.e. vector memory operations the
+            //  hand-counted vmcnt waits know nothing of)
+            const bool w1 = wave & 1;
+            f32x4 sa = aff_sc[h], sb = aff_sc[2 + h], ta = aff_sh[h], tb = aff_sh[2 + h];
+            asm volatile("" : "+v"(sa), "+v"(sb), "+v"(ta), "+v"(tb));
+            const f32x4 sc = w1 ? sb : sa, sh = w1 ? tb : ta;
+            aff_apply1(r, sc, sh);
+        }
+    };
     auto aff_write = [&](float *b, auto gc, auto jc, const AffPair &a) {
         constexpr int g = decltype(gc)::value;
         const bool in = (inmask >> g) & 1;
@@ -381,11 +408,14 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     int t_n = d_tc.n, t_ch = d_ch;  // INAFF: (sample, chunk) of the brick being staged - the DMA stream moves on before the brick is normalised
     if constexpr (INAFF) {  // the kernel's first brick: normalised here, exposed once
         AffPair a;
-        aff_read(lds, t_n, t_ch, I0{}, I0{}, a); aff_compute(a); aff_write(lds, I0{}, I0{}, a);
-        aff_read(lds, t_n, t_ch, I0{}, I1{}, a); aff_compute(a); aff_write(lds, I0{}, I1{}, a);
-        aff_read(lds, t_n, t_ch, I1{}, I0{}, a); aff_compute(a); aff_write(lds, I1{}, I0{}, a);
-        aff_read(lds, t_n, t_ch, I1{}, I1{}, a); aff_compute(a); aff_write(lds, I1{}, I1{}, a);
-        aff_read(lds, t_n, t_ch, I2{}, I0{}, a); aff_compute(a); aff_write(lds, I2{}, I0{}, a);
+        aff_table_load(t_n, t_ch);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        aff_table_landed();
+        aff_read(lds, I0{}, I0{}, a); aff_apply(I0{}, I0{}, I0{}, a); aff_apply(I0{}, I0{}, I1{}, a); aff_write(lds, I0{}, I0{}, a);
+        aff_read(lds, I0{}, I1{}, a); aff_apply(I0{}, I1{}, I0{}, a); aff_apply(I0{}, I1{}, I1{}, a); aff_write(lds, I0{}, I1{}, a);
+        aff_read(lds, I1{}, I0{}, a); aff_apply(I1{}, I0{}, I0{}, a); aff_apply(I1{}, I0{}, I1{}, a); aff_write(lds, I1{}, I0{}, a);
+        aff_read(lds, I1{}, I1{}, a); aff_apply(I1{}, I1{}, I0{}, a); aff_apply(I1{}, I1{}, I1{}, a); aff_write(lds, I1{}, I1{}, a);
+        aff_read(lds, I2{}, I0{}, a); aff_apply(I2{}, I0{}, I0{}, a); aff_apply(I2{}, I0{}, I1{}, a); aff_write(lds, I2{}, I0{}, a);
     }
     __syncthreads();
     f32x2 dA[8], dB[8], T[16], Y[16], V[2][16];
@@ -440,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
             const float *wch = wblk + (size_t)ch * (STEPS * 4 * 2048);
             const float *wnx = wblk + (size_t)(last_ch ? 0 : ch + 1) * (STEPS * 4 * 2048);
             W3_T(t_c1);
-            AffPair aff;
+            AffPair aff, aff2;
             static_for<0, STEPS>([&](auto st_c) {
                 constexpr int st = decltype(st_c)::value;
                 constexpr int pp = st & 1;
@@ -449,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                 // step finds its weights retired already (the epilogue waits for them before its stores); step 3 follows the
                 // chunk barrier's vmcnt(0)
                 if constexpr (st == 0) { if (ch != 0) W3_UWAIT(uc, 4); }
-                else if constexpr (st == 1) W3_UWAIT(uc, 4);
+                else if constexpr (st == 1) { W3_UWAIT(uc, 4); if constexpr (INAFF) aff_table_landed(); }
                 else if constexpr (st == 2) W3_UWAIT(uc, 2);  // (group 2 is two DMAs)
                 else W3_UWAIT(uc, 0);
                 const float *wn = (st + 1 < STEPS) ? wch + (size_t)(st + 1) * (4 * 2048) : wnx;
@@ -480,22 +510,29 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                     if constexpr (INAFF && st == 2) {
                         // the brick of chunk c + 1 (in the other buffer) is normalised here, in front of the barrier that publishes it.
                         // Groups 0 and 1 have landed (this step's weight wait left only group 2's two DMAs in flight); group 2 is
-                        // retired by vmcnt(8) at i = 27: only this step's eight weight loads are younger.
-                        if constexpr (i == 1) aff_read(bufn, t_n, t_ch, I0{}, I0{}, aff);
-                        if constexpr (i == 3) aff_compute(aff);
-                        if constexpr (i == 4) aff_write(bufn, I0{}, I0{}, aff);
-                        if constexpr (i == 8) aff_read(bufn, t_n, t_ch, I0{}, I1{}, aff);
-                        if constexpr (i == 10) aff_compute(aff);
-                        if constexpr (i == 11) aff_write(bufn, I0{}, I1{}, aff);
-                        if constexpr (i == 16) aff_read(bufn, t_n, t_ch, I1{}, I0{}, aff);
-                        if constexpr (i == 19) aff_compute(aff);
+                        // retired by vmcnt(8) at i = 24: only this step's eight weight loads (i < 16) are younger.
+                        // (two pairs in flight, each pair's arithmetic split over two gaps: 8 vector instructions per gap - 16 in one
+                        //  gap ran over the 64 cycles an MFMA covers; stamps: step 2 of this instantiation 3 578 cycles against 2 346)
+                        if constexpr (i == 1) aff_read(bufn, I0{}, I0{}, aff);
+                        if constexpr (i == 2) aff_read(bufn, I0{}, I1{}, aff2);
+                        if constexpr (i == 3) aff_apply(I0{}, I0{}, I0{}, aff);
+                        if constexpr (i == 4) aff_apply(I0{}, I0{}, I1{}, aff);
+                        if constexpr (i == 5) aff_write(bufn, I0{}, I0{}, aff);
+                        if constexpr (i == 8) aff_apply(I0{}, I1{}, I0{}, aff2);
+                        if constexpr (i == 9) aff_apply(I0{}, I1{}, I1{}, aff2);
+                        if constexpr (i == 10) aff_write(bufn, I0{}, I1{}, aff2);
+                        if constexpr (i == 11) aff_read(bufn, I1{}, I0{}, aff);
+                        if constexpr (i == 12) aff_read(bufn, I1{}, I1{}, aff2);
+                        if constexpr (i == 16) aff_apply(I1{}, I0{}, I0{}, aff);
+                        if constexpr (i == 19) aff_apply(I1{}, I0{}, I1{}, aff);
                         if constexpr (i == 20) aff_write(bufn, I1{}, I0{}, aff);
-                        if constexpr (i == 21) aff_read(bufn, t_n, t_ch, I1{}, I1{}, aff);
-                        if constexpr (i == 23) aff_compute(aff);
-                        if constexpr (i == 24) aff_write(bufn, I1{}, I1{}, aff);
-                        if constexpr (i == 26) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); aff_read(bufn, t_n, t_ch, I2{}, I0{}, aff); }
-                        if constexpr (i == 28) aff_compute(aff);
-                        if constexpr (i == 29) aff_write(bufn, I2{}, I0{}, aff);
+                        if constexpr (i == 21) aff_apply(I1{}, I1{}, I0{}, aff2);
+                        if constexpr (i == 22) aff_apply(I1{}, I1{}, I1{}, aff2);
+                        if constexpr (i == 23) aff_write(bufn, I1{}, I1{}, aff2);
+                        if constexpr (i == 24) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); aff_read(bufn, I2{}, I0{}, aff); }
+                        if constexpr (i == 26) aff_apply(I2{}, I0{}, I0{}, aff);
+                        if constexpr (i == 27) aff_apply(I2{}, I0{}, I1{}, aff);
+                        if constexpr (i == 28) aff_write(bufn, I2{}, I0{}, aff);
                     }
                     if constexpr ((MI355_W3_ABL & 4) == 0 && (i == 20 || i == 21)) {
                         typedef std::integral_constant<int, i - 20> Part;
@@ -513,6 +550,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                         if constexpr (i == 27) adv4b();
                         if constexpr (i == 28) adv5();
                     }
+                    if constexpr (INAFF && st == 0 && i == 17) aff_table_load(d_tc.n, d_ch);  // (the chunk whose DMA groups 1, 2 follow)
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 W3_T(t_s1);
