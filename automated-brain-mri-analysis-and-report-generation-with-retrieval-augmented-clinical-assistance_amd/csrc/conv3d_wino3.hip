@@ -448,6 +448,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
             hq_k[c] = c < p.head_ncls ? *(const f32x4 *)(p.head_w + c * p.Cout + (int)blockIdx.y * 32 + (lane & 7) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         hb_k = p.head_b[(lane & 7) < p.head_ncls ? (lane & 7) : 0];
     }
+    double stat_acc = 0.0;  // EPI 2, wave 0: this workgroup's quantised statistics of sample stat_n (lane = cout, statistic)
+    int stat_n = -1;
     int buf = 0;
     for (; tile < hi; tile += nl) {
         W3_T(t_t0);
@@ -716,17 +718,30 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                 }
             }
             if constexpr (EPI == 2) {
-                // the eight lanes with the same `piece` (lane bits 3..5) hold the same four couts of different voxels
+                // The eight lanes with the same `piece` (lane bits 3..5) hold the same four couts of different voxels: 8 values per lane
+                // (sum x and sum x^2 of 4 couts) to be added over those three lane bits.  A halving reduce-scatter (common.h,
+                // half32_reduce_scatter): v_permlane32_swap pairs lane ^ 32 (lanes 0-31 keep the sums, lanes 32-63 the sums of
+                // squares), v_permlane16_swap lane ^ 16 (rows 0, 2 keep couts 0, 1, rows 1, 3 couts 2, 3), one DPP row_ror:8 step
+                // lane ^ 8 - 7 additions and 6 swaps; every lane ends with ONE total.  (Was: a three-step __shfl_xor butterfly per
+                // value = 24 ds_bpermute round trips in dependent chains; stamps: this epilogue 6 100 cycles per tile against
+                // 4 270 without statistics.)
+                float y[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float a = st1[k], b = st2[k];
-#pragma unroll
-                    for (int m = 8; m < 64; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-                    if (lane_e < 8) {
-                        red[(wave * 32 + 4 * lane_e + k) * 2 + 0] = a;
-                        red[(wave * 32 + 4 * lane_e + k) * 2 + 1] = b;
-                    }
+                for (int k = 0; k < 4; k += 2) {
+                    float a0 = st1[k], a1 = st1[k + 1], c0 = st2[k], c1 = st2[k + 1];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1));
+                    y[k] = a0 + c0; y[k + 1] = a1 + c1;
                 }
+                float z0, z1;
+                {
+                    float a0 = y[0], a1 = y[1], c0 = y[2], c1 = y[3];
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1));
+                    z0 = a0 + c0; z1 = a1 + c1;
+                }
+                const bool b3 = lane_e & 8;
+                const float tot_l = (b3 ? z1 : z0) + dpp_perm<0x128>(b3 ? z0 : z1);  // row_ror:8 = lane ^ 8
+                // this lane's value: statistic lane >> 5, cout 4 piece + 2 (lane >> 4 & 1) + (lane >> 3 & 1)
+                red[(wave * 32 + 4 * piece + 2 * ((lane_e >> 4) & 1) + ((lane_e >> 3) & 1)) * 2 + (lane_e >> 5)] = tot_l;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -735,7 +750,14 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                     double tot = 0.0;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) tot += (double)red[(w * 32 + c) * 2 + k];
-                    atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co0 + c) * 2 + k, quantise_partial(tot, k, (long)p.D * p.H * p.W));  // exact, order-independent (common.h)
+                    // quantised partials add exactly in fp64 in any order (common.h): they are gathered per workgroup and sample and
+                    // go out as ONE atomic per (sample, cout, statistic) and workgroup instead of one per tile - 65 536 tiles of a
+                    // 128^3 x 8 layer were 4.2 M fp64 atomics on 512 addresses
+                    if (cur.n != stat_n) {
+                        if (stat_n >= 0) atomicAdd(p.stats + ((size_t)stat_n * p.Cout + co0 + c) * 2 + k, stat_acc);
+                        stat_acc = 0.0; stat_n = cur.n;
+                    }
+                    stat_acc += quantise_partial(tot, k, (long)p.D * p.H * p.W);
                 }
             }
         }
@@ -743,6 +765,10 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         W3_T(t_e2);
         W3_ACC(4, t_e0, t_e2);
         W3_CNT(7);
+    }
+    if constexpr (EPI == 2) {
+        if (wave == 0 && stat_n >= 0)
+            atomicAdd(p.stats + ((size_t)stat_n * p.Cout + (int)blockIdx.y * 32 + (lane >> 1)) * 2 + (lane & 1), stat_acc);
     }
     W3_T(t_kernel1);
     W3_ACC(5, t_kernel0, t_kernel1);
