@@ -38,6 +38,8 @@ CONV_CASES = [
     (2, 64, 64, 128, 32, 64, 2, 1),    # stride 2, >= 1024 tiles: the persistent LDS-DMA stride-2 kernel
     (3, 50, 62, 90, 16, 128, 2, 0),    # the same kernel: ragged in z, y, x (odd input dims), 2 chunks, two cout blocks, batch
     (8, 32, 30, 32, 128, 256, 2, 1),   # the same kernel on a narrow volume (Wo = 16): 2 x 4 x 16 tiles, ragged y, 16 chunks
+    (8, 4, 16, 16, 128, 128, 1, 1),    # one z tile (both z borders in every brick), 2 x 2 tiles in y, x: 128 units of 8 chunks -> F(2x2x2,3x3x3)
+    (4, 8, 8, 24, 128, 160, 1, 0),     # the same rule on an odd tile grid (2 x 1 x 3 tiles, linear order), 5 cout blocks, batch 4 (120 units), no activation
     (8, 8, 8, 8, 320, 320, 1, 1),      # deep level: 160 (tile, cout block) units of 20 chunks -> F(2x2x2,3x3x3) (MI355_WINO3=0: split-K over the 40 chunks)
     (8, 16, 16, 16, 256, 320, 2, 0),   # deep stride-2 level: split-K (4 slices), no activation
     (2, 4, 4, 4, 320, 320, 1, 1),      # bottleneck-sized launch: split-K with a 64-voxel volume in 256-voxel tiles
@@ -60,6 +62,8 @@ F32_EXPECT_KERNEL = {
     (3, 30, 37, 70, 48, 32, 1, 0): "conv3_f32_wino2_kernel<0>",
     (2, 30, 64, 128, 32, 32, 1, 0): "conv3_f32_wino2_kernel<0>",
     (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f32_s2dma_kernel<5>",
+    (8, 4, 16, 16, 128, 128, 1, 1): "conv3_f32_wino3_kernel<0, false>",
+    (4, 8, 8, 24, 128, 160, 1, 0): "conv3_f32_wino3_kernel<0, false>",
     (8, 8, 8, 8, 320, 320, 1, 1): "conv3_f32_wino3_kernel<0, false>",   # the 8^3 level of a batch of eight tiles: 160 units of 20 chunks
 }
 
