@@ -78,6 +78,9 @@ __device__ unsigned long long w3_stamps[1024 * 16];
 #ifndef MI355_W3_PIN
 #define MI355_W3_PIN 1   // epilogue phase 1: the accumulator reads are pinned every MI355_W3_PIN register pairs (see there)
 #endif
+#ifndef MI355_W3_TWOBODY
+#define MI355_W3_TWOBODY 0  // 1: a second copy of the chunk body for a tile's chunk 0 (see the tile loop)
+#endif
 #ifndef MI355_W3_ABL
 #define MI355_W3_ABL 0  // ablation bits (probe only, results wrong): 1 no epilogue, 4 no brick DMA, 8 no weight loads, 16 no input transform, 32 no stores
 #endif
@@ -454,10 +457,12 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     for (; tile < hi; tile += nl) {
         W3_T(t_t0);
         f32x16 acc[16];
+#if !MI355_W3_TWOBODY
 #pragma unroll
         for (int f = 0; f < 16; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+#endif
         const int ntile = tile + nl;
         const TileCoord nxt_tile = ntile < hi ? decode(ntile) : cur;
         W3_T(t_t1);
@@ -465,7 +470,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         // (Tried in round 4: a second copy of the chunk body for chunk 0 whose first MFMAs take the constant 0 as C, which saves the
         // 256 v_accvgpr_write above - 1 100 cycles of the pipe the f32 MFMAs run on, 3.5 % of a 32 -> 32 tile.  The build with two
         // bodies ends in a memory access fault on every shape although its ISA reads correctly; not found, reverted.)
-        for (int ch = 0; ch < p.nchunks; ++ch) {
+        auto chunk_body = [&](auto first_c, const int ch) {
+            constexpr bool FIRST = decltype(first_c)::value;  // two-body build: a tile's chunk 0, whose first MFMAs take C = 0
             const bool last_ch = ch == p.nchunks - 1;
             const float *bufc = lds + buf * W3_BUF;
             float *bufn = lds + (buf ^ 1) * W3_BUF;
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                 // this step's weights: everything older than the 4 brick DMAs the previous step issued behind them.  A tile's first
                 // step finds its weights retired already (the epilogue waits for them before its stores); step 3 follows the
                 // chunk barrier's vmcnt(0)
-                if constexpr (st == 0) { if (ch != 0) W3_UWAIT(uc, 4); }
+                if constexpr (st == 0) { if constexpr (!FIRST) { if (MI355_W3_TWOBODY || ch != 0) W3_UWAIT(uc, 4); } }
                 else if constexpr (st == 1) { W3_UWAIT(uc, 4); if constexpr (INAFF) aff_table_landed(); }
                 else if constexpr (st == 2) W3_UWAIT(uc, 2);  // (group 2 is two DMAs)
                 else W3_UWAIT(uc, 0);
@@ -491,6 +497,10 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                 static_for<0, 32>([&](auto i_c) {
                     constexpr int i = decltype(i_c)::value;
                     constexpr int f = i & 15, j = i >> 4;
+                    if constexpr (FIRST && st == 0 && j == 0) {
+                        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(uq[pp][f >> 1][(f & 1) * 2 + j], V[pp][f][j], zero16, 0, 0, 0);
+                    } else
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(uq[pp][f >> 1][(f & 1) * 2 + j], V[pp][f][j], acc[f], 0, 0, 0);
                     if constexpr ((MI355_W3_ABL & 16) == 0) {
                         // V of the next quad, dealt over the MFMA gaps in bunches (a gap that holds VALU work costs the matrix
@@ -570,7 +580,13 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
             W3_ACC(10, t_c1, t_c4);
             buf ^= 1;
             W3_CNT(6);
-        }
+        };
+#if MI355_W3_TWOBODY
+        chunk_body(std::true_type{}, 0);
+        for (int ch = 1; ch < p.nchunks; ++ch) chunk_body(std::false_type{}, ch);
+#else
+        for (int ch = 0; ch < p.nchunks; ++ch) chunk_body(std::false_type{}, ch);
+#endif
         W3_T(t_e0);
         if constexpr ((MI355_W3_ABL & 1) != 0) {
 #pragma unroll
