@@ -80,16 +80,37 @@ def _build_lock():
             fcntl.flock(fh, fcntl.LOCK_UN)
 
 
+def _listing(src: Path) -> Path:
+    """the device assembly listing kept beside the object of `src` (what the ISA gate reads)"""
+    return OBJ_DIR / (src.stem + ".gfx950.s")
+
+
 def _compile(hipcc: str, src: Path, obj: Path, verbose: bool):
-    tmp = obj.with_suffix(f".o.{os.getpid()}.tmp")
-    cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(tmp)]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        tmp.unlink(missing_ok=True)
-        raise RuntimeError(f"hipcc failed on {src.name}:\n" + res.stdout + res.stderr)
-    os.replace(tmp, obj)
+    """One source -> one object, in a private temporary directory (-save-temps=obj leaves the device listing there), then the ISA
+    gate (_isa_gate.py: no scratch in the hand-counted kernels, no un-padded hazard inside inline asm) on that listing.  A listing
+    that fails the gate fails the build: the object is not installed."""
+    from . import _isa_gate
+    tmpdir = OBJ_DIR / f".tmp.{src.stem}.{os.getpid()}"
+    shutil.rmtree(tmpdir, ignore_errors=True)
+    tmpdir.mkdir(parents=True)
+    try:
+        tmp = tmpdir / (src.stem + ".o")
+        cmd = [hipcc, *FLAGS, "-save-temps=obj", "-c", str(src), "-o", str(tmp)]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src.name}:\n" + res.stdout + res.stderr)
+        lst = tmpdir / (src.stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        if not lst.exists():
+            raise RuntimeError(f"hipcc left no device listing for {src.name} (-save-temps=obj): the ISA gate cannot run")
+        findings = _isa_gate.check_asm_file(lst)
+        os.replace(lst, _listing(src))   # (kept for inspection, also when the gate fails)
+        if findings and os.environ.get("MI355_ISA_GATE", "1") != "0":
+            raise RuntimeError(f"ISA gate failed on {src.name} ({len(findings)} findings; listing: {_listing(src)}):\n" + "\n".join(findings[:20]))
+        os.replace(tmp, obj)
+    finally:
+        shutil.rmtree(tmpdir, ignore_errors=True)
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:

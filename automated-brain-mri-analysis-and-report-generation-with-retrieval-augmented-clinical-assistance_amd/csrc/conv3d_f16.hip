@@ -1161,8 +1161,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                                 // (s_nop 1 behind the store: a VALU write of the data registers of a 16-byte store needs a wait state after
                                 //  its issue - hipcc pads its own stores, it does not look into inline asm, and the next pair's v_cvt_pk
                                 //  reuses these four registers at once: without the pad the statistics instantiations stored garbage)
-                                if constexpr (MI355_H16_SC1 != 0) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lo), "v"(v), "s"(row) : "memory");
-                                else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lo), "v"(v), "s"(row) : "memory");
+                                if constexpr (MI355_H16_SC1 != 0) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lo), "v"(v), "s"(row) : "memory");
+                                else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lo), "v"(v), "s"(row) : "memory");
                             } else {
                                 *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + (nf * 32 + 8 * gp) * 2) = val2[0];
                                 *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + (nf * 32 + 8 * gp + 8) * 2) = val2[1];
@@ -1173,9 +1173,12 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                         // half-wave (x 4 fragments = this wave's 128 voxels) and adds it itself - no LDS, no barrier; round 2
                         // reduced 32 values with butterflies, crossed the four waves through LDS and two __syncthreads().
                         // Quantised partials: exact additions in any order (common.h).
-                        const float tot = half32_reduce_scatter(s1, s2, lane);
-                        const int r = stat_slot_r(lane), k = (lane >> 4) & 1;
-                        const int c = nf * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                        // (lane-dependent address parts from the laundered lane id `ln`: as tile-loop invariants of the plain lane id the
+                        //  64-bit statistics address was hoisted to the kernel entry and spilled - 12 bytes of scratch, reloaded here by
+                        //  vector-memory operations the hand-counted waits of the weight ring know nothing of; round 5)
+                        const float tot = half32_reduce_scatter(s1, s2, ln);
+                        const int r = stat_slot_r(ln), k = (ln >> 4) & 1;
+                        const int c = nf * 32 + 8 * (r >> 2) + 4 * (ln >> 5) + (r & 3);
                         atomicAdd(p.stats + ((size_t)cur.n * p.Cout + co_blk + c) * 2 + k, quantise_partial((double)tot, k, (long)p.Do * p.Ho * p.Wo));
                     }
                 });
@@ -1201,8 +1204,8 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                 const unsigned lo = lane_off;
                 // sc1: the output lines leave the XCD's L2 with the store - nothing on this XCD reads them again, and kept there
                 // they evict the brick lines whose next 32 bytes the next channel chunk is about to fetch
-                if constexpr (MI355_H16_SC1 != 0) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 0" ::"v"(lo), "v"(v), "s"(row) : "memory");
-                else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 0" ::"v"(lo), "v"(v), "s"(row) : "memory");
+                if constexpr (MI355_H16_SC1 != 0) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 0" ::"v"(lo), "v"(v), "s"(row) : "memory");
+                else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 0" ::"v"(lo), "v"(v), "s"(row) : "memory");
             });
             }
         }

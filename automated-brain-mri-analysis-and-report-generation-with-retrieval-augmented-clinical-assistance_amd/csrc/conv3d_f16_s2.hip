@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
                     const unsigned lo2 = lane_off;
                     // sc1: nothing on this XCD reads the output again; kept in its L2 the lines would evict brick lines.  s_nop 1: a
                     // VALU write of a 16-byte store's data registers needs a wait state after its issue (the next pair reuses them)
-                    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lo2), "v"(v), "s"(rowp) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lo2), "v"(v), "s"(rowp) : "memory");
                 }
             if constexpr (STATS) {
                 // transposing reduction over the 32 voxel lanes (common.h): each lane ends with the total of one (cout, statistic)

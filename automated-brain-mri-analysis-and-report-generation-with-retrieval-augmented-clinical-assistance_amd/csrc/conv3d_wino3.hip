@@ -79,7 +79,7 @@ __device__ unsigned long long w3_stamps[1024 * 16];
 #define MI355_W3_PIN 1   // epilogue phase 1: the accumulator reads are pinned every MI355_W3_PIN register pairs (see there)
 #endif
 #ifndef MI355_W3_TWOBODY
-#define MI355_W3_TWOBODY 0  // 1: a second copy of the chunk body for a tile's chunk 0 (see the tile loop)
+#define MI355_W3_TWOBODY 1  // a second copy of the chunk body for a tile's chunk 0 whose first MFMAs take C = 0 (see the tile loop); 0: one body
 #endif
 #ifndef MI355_W3_ABL
 #define MI355_W3_ABL 0  // ablation bits (probe only, results wrong): 1 no epilogue, 4 no brick DMA, 8 no weight loads, 16 no input transform, 32 no stores
@@ -215,6 +215,13 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     // before the first use of an ordinary load).
     const float *wblk = p.wp + (size_t)blockIdx.y * p.nchunks * (STEPS * 4 * 2048) + wave * 2048;
     const unsigned wl0 = lane * 16, wl1 = lane * 16 + 4096;
+// W3_ULOAD0 = the first load of a group: SBASE may have been reloaded from an SGPR spill lane (v_readlane_b32, a VALU write of an
+// SGPR) right in front of the statement, and a vector-memory instruction that reads such an SGPR as its scalar base needs five
+// wait states which hipcc pads for its own instructions only, not inside inline asm (cdna_hip_programming.md 5.7 item 2).
+// Without them the load reads the PREVIOUS contents of the pair: a wild address - round 4's "memory access fault on every
+// shape" of the two-body build (its listing carries exactly this sequence; _isa_gate.py H1 now fails the build on it).
+#define W3_ULOAD0(DST, VOFF, SBASE, IMM) \
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(DST) : "v"(VOFF), "s"(SBASE), "n"(IMM) : "memory")
 #define W3_ULOAD(DST, VOFF, SBASE, IMM) \
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(DST) : "v"(VOFF), "s"(SBASE), "n"(IMM) : "memory")
 #define W3_UWAIT(U, N)                                                                                                 \
@@ -289,6 +296,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         unsigned zoff = 0;
         asm volatile("" : "+v"(zoff));
 #define W3_TLOAD(DST, SBASE, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(DST) : "v"(zoff), "s"(SBASE), "n"(IMM) : "memory")
+        asm volatile("s_nop 4" ::: "memory");  // (q, r come straight from v_readfirstlane_b32: the five wait states of W3_ULOAD0)
         W3_TLOAD(aff_sc[0], q, 0); W3_TLOAD(aff_sc[1], q, 16); W3_TLOAD(aff_sc[2], q, 32); W3_TLOAD(aff_sc[3], q, 48);
         W3_TLOAD(aff_sh[0], r, 0); W3_TLOAD(aff_sh[1], r, 16); W3_TLOAD(aff_sh[2], r, 32); W3_TLOAD(aff_sh[3], r, 48);
 #undef W3_TLOAD
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
     static_for<0, 8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         auto &u0 = uq[0]; const unsigned wl = k < 4 ? wl0 : wl1; const float *wb = wblk;
-        W3_ULOAD(u0[k], wl, wb, (k & 3) * 1024);
+        if constexpr (k == 0) W3_ULOAD0(u0[k], wl, wb, (k & 3) * 1024); else W3_ULOAD(u0[k], wl, wb, (k & 3) * 1024);
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int t_n = d_tc.n, t_ch = d_ch;  // INAFF: (sample, chunk) of the brick being staged - the DMA stream moves on before the brick is normalised
@@ -467,9 +475,12 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
         const TileCoord nxt_tile = ntile < hi ? decode(ntile) : cur;
         W3_T(t_t1);
         W3_ACC(9, t_t0, t_t1);
-        // (Tried in round 4: a second copy of the chunk body for chunk 0 whose first MFMAs take the constant 0 as C, which saves the
-        // 256 v_accvgpr_write above - 1 100 cycles of the pipe the f32 MFMAs run on, 3.5 % of a 32 -> 32 tile.  The build with two
-        // bodies ends in a memory access fault on every shape although its ISA reads correctly; not found, reverted.)
+        // Two bodies (MI355_W3_TWOBODY, round 5): a second copy of the chunk body for a tile's chunk 0 whose first MFMAs take the
+        // constant 0 as C saves the 256 v_accvgpr_write of the accumulator clear (1 - 3 % per launch, tools/wino3_probe).  Round 4
+        // abandoned it after "a memory access fault on every shape".  The cause, from that build's listing: with the second body
+        // the allocator spilled the weight base of a step to a VGPR lane and reloaded it (v_readlane_b32) one instruction in
+        // front of the inline-asm load that uses it as scalar base - five wait states short (W3_ULOAD0 above).  The build gate
+        // (_isa_gate.py) checks every listing for that sequence; positive and negative control in profiles/r05_wino3_two_body.txt.
         auto chunk_body = [&](auto first_c, const int ch) {
             constexpr bool FIRST = decltype(first_c)::value;  // two-body build: a tile's chunk 0, whose first MFMAs take C = 0
             const bool last_ch = ch == p.nchunks - 1;
@@ -517,7 +528,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f32_wino3_kernel(Wino3Args p) {
                     if constexpr (i < 16 && (i & 1) == 0) {  // the next step's weights - unconditionally: a branch per load would cut
                         constexpr int k = i >> 1;            // the MFMA stream into basic blocks.  A tile's last step fetches the next
                         auto &un = uq[pp ^ 1]; const unsigned wl = k < 4 ? wl0 : wl1; const float *wb = wn;  // tile's first fragments
-                        if constexpr ((MI355_W3_ABL & 8) == 0) W3_ULOAD(un[k], wl, wb, (k & 3) * 1024);      // (same cout block, chunk 0)
+                        if constexpr ((MI355_W3_ABL & 8) == 0) {                                               // (same cout block, chunk 0)
+                            if constexpr (k == 0) W3_ULOAD0(un[k], wl, wb, (k & 3) * 1024); else W3_ULOAD(un[k], wl, wb, (k & 3) * 1024);
+                        }
                     }
                     if constexpr (INAFF && st == 2) {
                         // the brick of chunk c + 1 (in the other buffer) is normalised here, in front of the barrier that publishes it.

@@ -155,3 +155,63 @@ def test_bench_self_launch_command(monkeypatch):
     bench.maybe_self_launch(args, ["--gpus", "2"])
     bench.maybe_self_launch(bench.parse_args([]), [])                      # N = 1: nothing is started
     assert not calls
+
+
+# ---------------------------------------------------------------- ISA gate of the build (round 5; _isa_gate.py)
+_GATE_KERNEL = """\t.text
+_ZN5mi35520conv3_f16_dma_kernelILb0ELb0EEEvNS_9ConvArgsHE:
+\ts_load_dwordx2 s[0:1], s[4:5], 0x0
+\tv_writelane_b32 v254, s0, 0
+\tv_writelane_b32 v254, s1, 1
+%s
+\ts_endpgm
+\t.amdgpu_metadata
+amdhsa.kernels:
+  - .agpr_count:     128
+    .name:           _ZN5mi35520conv3_f16_dma_kernelILb0ELb0EEEvNS_9ConvArgsHE
+    .private_segment_fixed_size: %d
+    .sgpr_count:     100
+    .sgpr_spill_count: 2
+    .vgpr_count:     300
+    .vgpr_spill_count: %d
+"""
+
+
+def test_isa_gate_flags_the_hazards_it_is_there_for(amd):
+    """The three ways a compiler bump or an edit can silently break the hand-counted kernels (the cause of round 4's
+    wino3 two-body fault): a spilled SGPR reloaded straight in front of an inline-asm load that uses it as scalar base, a compiler
+    copy of a register an inline-asm load is still in flight to, scratch in a hand-counted kernel."""
+    gate = amd._isa_gate
+    hazard = ("\tv_readlane_b32 s0, v254, 0\n\tv_readlane_b32 s1, v254, 1\n\t;;#ASMSTART\n\tglobal_load_dwordx4 v[4:7], v1, s[0:1] offset:0\n\t;;#ASMEND\n"
+              "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND")
+    f = gate.check_asm_text(_GATE_KERNEL % (hazard, 0, 0))
+    assert len(f) == 2 and all(x.startswith("H1") for x in f), f
+    padded = hazard.replace("\tglobal_load_dwordx4", "\ts_nop 4\n\tglobal_load_dwordx4")
+    assert gate.check_asm_text(_GATE_KERNEL % (padded, 0, 0)) == []
+    # the same reload in front of a COMPILER-emitted load is the hazard recogniser's business, not the gate's
+    plain = hazard.replace("\t;;#ASMSTART\n\tglobal_load", "\tglobal_load").replace("offset:0\n\t;;#ASMEND", "offset:0")
+    assert gate.check_asm_text(_GATE_KERNEL % (plain, 0, 0)) == []
+    copy = ("\t;;#ASMSTART\n\tglobal_load_dwordx4 v[4:7], v1, s[0:1] offset:0\n\t;;#ASMEND\n\tv_mov_b32_e32 v9, v5\n"
+            "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND")
+    f = gate.check_asm_text(_GATE_KERNEL % (copy, 0, 0))
+    assert len(f) == 1 and f[0].startswith("H2"), f
+    waited = copy.replace("\tv_mov_b32_e32 v9, v5\n", "").replace("vmcnt(0)\n\t;;#ASMEND", "vmcnt(0)\n\t;;#ASMEND\n\tv_mov_b32_e32 v9, v5")
+    assert gate.check_asm_text(_GATE_KERNEL % (waited, 0, 0)) == []
+    f = gate.check_asm_text(_GATE_KERNEL % ("\ts_nop 0", 12, 2))
+    assert len(f) == 1 and f[0].startswith("R "), f
+
+
+def test_built_library_passes_the_isa_gate(amd):
+    """Every listing the build left beside its objects passes the gate (the build itself refuses a listing that does not)."""
+    import glob
+    lst = sorted(glob.glob(os.path.join(os.path.dirname(str(amd._lib.lib_path())), "obj", "*.gfx950.s")))
+    if not lst:
+        pytest.skip("library built elsewhere: no listings beside it")
+    gate = amd._isa_gate
+    names = set()
+    for path in lst:
+        assert gate.check_asm_file(path) == [], path
+        names |= {gate.demangle(n) for n in gate.resources(open(path).read())}
+    # the gate knows the hand-counted kernels by name: a rename must not silently drop one out of the scratch check
+    for prefix in ("conv3_f32_wino3_kernel", "conv3_f32_wino2_kernel", "conv3_f32_s2dma_kernel", "conv3_f16_dma_kernel", "conv3_f16_s2dma_kernel"):
+        assert any(prefix in n for n in names), prefix
