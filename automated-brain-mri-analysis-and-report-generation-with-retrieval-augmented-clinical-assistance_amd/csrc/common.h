@@ -19,12 +19,13 @@ void set_error(const char *fmt, ...);
 // MI355_ERR_NO_DEVICE when no gfx950 device is visible.
 int bind_device();
 
-// Process-wide scratch on the bound device, one buffer per slot, grown on demand (synchronise, free, allocate) under a
-// mutex and never freed per call; `zeroed` buffers are cleared when (re)allocated.  Work that uses a slot is ordered
-// by the caller's stream: one stream at a time per process ("Stream semantics").
+// Process-wide scratch on the bound device, one buffer per (lane, slot) - a lane = one of the first few streams the caller
+// launches on (unet.hip, "Lanes") -, grown on demand (synchronise, free, allocate) under a mutex and never freed per call;
+// `zeroed` buffers are cleared when (re)allocated.  Work that uses a slot is ordered by the stream it was asked for
+// ("Stream semantics").
 enum ScratchSlot { SCR_ARENA = 0, SCR_SW_AGG, SCR_SPLITK_F32, SCR_SPLITK_F16, SCR_ZEROS, SCR_ZERO_BIAS, SCR_SMALL, SCR_TOPK,
                    SCR_CROP, SCR_ZSCORE, SCR_RESAMPLE, SCR_RESAMPLE_MM, SCR_COUNT };
-int device_scratch(int slot, size_t bytes, void **out, bool zeroed = false);
+int device_scratch(int slot, hipStream_t stream, size_t bytes, void **out, bool zeroed = false);
 
 #define MI355_HIP(expr)                                                                    \
     do {                                                                                   \

@@ -1791,7 +1791,7 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
                 attr_set = true;
             }
             float *zeros = nullptr;  // the zero page out-of-volume DMA pieces read
-            MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
+            MI355_TRY(device_scratch(SCR_ZEROS, s, 256, (void **)&zeros, true));
             const int epi = c.head_out ? 1 : (c.stats ? 2 : 0);
             static const char *const w2_names[3] = {"conv3_f32_wino2_kernel<0>", "conv3_f32_wino2_kernel<1>", "conv3_f32_wino2_kernel<2>"};
             *kernel_name = w.wino2 ? w2_names[epi] : "conv3_f32_wino_kernel";
@@ -1852,8 +1852,8 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
                 float *partial = nullptr, *zero_bias = nullptr;
                 const long out_elems = (long)c.N * a.Do * a.Ho * a.Wo * w.cout;
                 const size_t need = (size_t)S * out_elems * sizeof(float);
-                MI355_TRY(device_scratch(SCR_ZERO_BIAS, 4096 * sizeof(float), (void **)&zero_bias, true));
-                MI355_TRY(device_scratch(SCR_SPLITK_F32, need, (void **)&partial));
+                MI355_TRY(device_scratch(SCR_ZERO_BIAS, s, 4096 * sizeof(float), (void **)&zero_bias, true));
+                MI355_TRY(device_scratch(SCR_SPLITK_F32, s, need, (void **)&partial));
                 b.ksplit = S; b.partial = partial; b.zero_bias = zero_bias; b.out_elems = out_elems;
                 const size_t lds_bytes = brick_bytes < 4096 ? 4096 : brick_bytes;
                 dim3 grid((unsigned)tiles, gy, S);
@@ -1933,7 +1933,7 @@ int conv3d_mfma_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, cons
                 attr_set = true;
             }
             float *zeros = nullptr;
-            MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
+            MI355_TRY(device_scratch(SCR_ZEROS, s, 256, (void **)&zeros, true));
             Wino2Args wa;
             wa.c = b; wa.total_tiles = (int)tiles; wa.zeros = zeros;
             wa.order = make_tile_order(b.tiles_x, b.tiles_y, b.tiles_z);

@@ -1377,7 +1377,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
                 float *partial = nullptr;
                 const long out_elems = (long)c.N * a.Do * a.Ho * a.Wo * w.cout;
                 const size_t need = (size_t)S * out_elems * sizeof(float);
-                MI355_TRY(device_scratch(SCR_SPLITK_F16, need, (void **)&partial));
+                MI355_TRY(device_scratch(SCR_SPLITK_F16, s, need, (void **)&partial));
                 b.ksplit = S; b.partial = partial; b.out_elems = out_elems;
                 dim3 grid((unsigned)tiles, gy, S);
                 int rc;
@@ -1411,7 +1411,7 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
             (long)10 * c.Hi * c.Wi < (1l << 24) && ((long)10 * c.Hi * c.Wi + 8l * c.Di * c.Hi * c.Wi) * 16 < (1l << 32) &&
             (!c.in_scale || (c.C1 == 0 && tab_bytes <= (size_t)GA::TAB_MAX_BYTES))) {
             void *zeros = nullptr;  // the zero page out-of-volume DMA pieces read
-            MI355_TRY(device_scratch(SCR_ZEROS, 256, &zeros, true));
+            MI355_TRY(device_scratch(SCR_ZEROS, s, 256, &zeros, true));
             b.zeros = zeros;
             b.total_tiles = (int)tiles;
             b.order = make_tile_order(b.tiles_x, b.tiles_y, b.tiles_z);

@@ -345,7 +345,7 @@ int conv3d_f16_s2dma(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, c
     a.div_tiles_per_n = make_fastdiv(tiles_x * tiles_y * tiles_z);
     a.order = make_tile_order(tiles_x, tiles_y, tiles_z);
     void *zeros = nullptr;
-    MI355_TRY(device_scratch(SCR_ZEROS, 256, &zeros, true));
+    MI355_TRY(device_scratch(SCR_ZEROS, s, 256, &zeros, true));
     a.zeros = zeros;
     int gx = 256 / gy;
     gx = gx < 8 ? 8 : (gx / 8) * 8;

@@ -911,7 +911,7 @@ int conv3d_wino3_f32(const ConvWeights &w, const ConvCall &c, hipStream_t s, con
     a.head_w = c.head_w; a.head_b = c.head_b; a.head_out = c.head_out; a.head_ncls = c.head_ncls;
     a.in_scale = c.in_scale; a.in_shift = c.in_shift; a.in_slope = c.in_act == ACT_LRELU ? c.slope : 1.0f;
     float *zeros = nullptr;
-    MI355_TRY(device_scratch(SCR_ZEROS, 256, (void **)&zeros, true));
+    MI355_TRY(device_scratch(SCR_ZEROS, s, 256, (void **)&zeros, true));
     a.zeros = zeros;
     static bool attr_set = false;
     if (!attr_set) {

@@ -780,7 +780,7 @@ extern "C" int mi355_zscore_masked(float *vol_dev, const uint8_t *mask_dev, int 
     // used to sit in SCR_SMALL, which mi355_label_confusion / mi355_label_stats also use: a caller following INTEGRATION.md's
     // two-stream exception (preprocess the next case beside a prediction / evaluation) would have corrupted mean and std.
     double *sums = nullptr;
-    MI355_TRY(device_scratch(SCR_ZSCORE, (size_t)(64 + 64 * 2048) * 3 * sizeof(double), (void **)&sums));
+    MI355_TRY(device_scratch(SCR_ZSCORE, s, (size_t)(64 + 64 * 2048) * 3 * sizeof(double), (void **)&sums));
     double *partial = sums + 64 * 3;
     hipLaunchKernelGGL(masked_sums_kernel, dim3((unsigned)blocks, C), dim3(256), 0, s, vol_dev, mask_dev, voxels, partial);
     hipLaunchKernelGGL(masked_sums_finish_kernel, dim3(C), dim3(192), 0, s, partial, (int)blocks, sums);

@@ -101,7 +101,7 @@ extern "C" int mi355_label_confusion(const uint8_t *pred_dev, const uint8_t *gt_
     MI355_REQUIRE(pred_dev && gt_dev && counts_host && K >= 2 && K <= 8, "bad argument (2 <= K <= 8)");
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *c = nullptr;
-    MI355_TRY(device_scratch(SCR_SMALL, 1 << 20, (void **)&c));
+    MI355_TRY(device_scratch(SCR_SMALL, s, 1 << 20, (void **)&c));
     MI355_HIP(hipMemsetAsync(c, 0, 64 * sizeof(unsigned long long), s));
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -122,7 +122,7 @@ extern "C" int mi355_cosine_topk(const float *vectors_dev, const float *query_de
     hipStream_t s = (hipStream_t)stream;
     // scratch: [best u64 | out_s 64 f32 | taken 64 i32 | out_i 64 i32 | scores N f32], persistent across calls
     char *scr = nullptr;
-    MI355_TRY(device_scratch(SCR_TOPK, 1024 + (size_t)N * sizeof(float), (void **)&scr));
+    MI355_TRY(device_scratch(SCR_TOPK, s, 1024 + (size_t)N * sizeof(float), (void **)&scr));
     unsigned long long *best = (unsigned long long *)scr;
     float *out_s = (float *)(scr + 64);
     int *taken = (int *)(scr + 64 + 256), *out_i = (int *)(scr + 64 + 512);
@@ -225,7 +225,7 @@ extern "C" int mi355_crop_mask(const float *vol_dev, int C, int Z, int Y, int X,
     hipStream_t s = (hipStream_t)stream;
     const int64_t V = (int64_t)Z * Y * X;
     char *scr = nullptr;   // persistent: [flags 8 i32 | pad to 256 | state V u8]
-    MI355_TRY(device_scratch(SCR_CROP, 256 + (size_t)V, (void **)&scr));
+    MI355_TRY(device_scratch(SCR_CROP, s, 256 + (size_t)V, (void **)&scr));
     int *flags = (int *)scr;  // [0] = changed, [1..6] = bbox
     uint8_t *state = (uint8_t *)(scr + 256);
     int64_t blocks = (V + 255) / 256;
@@ -298,7 +298,7 @@ extern "C" int mi355_label_stats(const uint8_t *seg_dev, int d0, int d1, int d2,
     hipStream_t s = (hipStream_t)stream;
     long long init[80], *dev = nullptr;
     for (int i = 0; i < 80; ++i) init[i] = (i % 10 >= 4 && i % 10 <= 6) ? (1ll << 40) : (i % 10 >= 7 ? -1 : 0);
-    MI355_TRY(device_scratch(SCR_SMALL, 1 << 20, (void **)&dev));
+    MI355_TRY(device_scratch(SCR_SMALL, s, 1 << 20, (void **)&dev));
     hipError_t e = hipMemcpyAsync(dev, init, sizeof(init), hipMemcpyHostToDevice, s);
     const int64_t V = (int64_t)d0 * d1 * d2;
     int64_t blocks = (V + 255) / 256;

@@ -170,7 +170,7 @@ extern "C" int mi355_resize_axis(const float *in_dev, float *out_dev, int64_t ou
     else if (order == 1) hipLaunchKernelGGL(resize_axis_kernel<1>, dim3(blocks), dim3(256), 0, s, in_dev, out_dev, (long)outer, n_in, n_out, (long)inner, scale);
     else {
         float *coef = nullptr;
-        MI355_TRY(device_scratch(SCR_RESAMPLE, (size_t)outer * (n_in + 2 * RS_PAD) * inner * sizeof(float), (void **)&coef));
+        MI355_TRY(device_scratch(SCR_RESAMPLE, s, (size_t)outer * (n_in + 2 * RS_PAD) * inner * sizeof(float), (void **)&coef));
         const int64_t lines = outer * inner;
         hipLaunchKernelGGL(spline3_prefilter_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, in_dev, coef, (long)outer, n_in, (long)inner);
         hipLaunchKernelGGL(resize_axis_kernel<3>, dim3(blocks), dim3(256), 0, s, (const float *)coef, out_dev, (long)outer, n_in, n_out, (long)inner, scale);
@@ -185,7 +185,7 @@ extern "C" int mi355_clip_to_range_of(float *x_dev, int64_t groups, int64_t n_pe
     MI355_TRY(bind_device());
     hipStream_t s = (hipStream_t)stream;
     unsigned *mm = nullptr;
-    MI355_TRY(device_scratch(SCR_RESAMPLE_MM, (size_t)65536 * 2 * sizeof(unsigned), (void **)&mm));
+    MI355_TRY(device_scratch(SCR_RESAMPLE_MM, s, (size_t)65536 * 2 * sizeof(unsigned), (void **)&mm));
     hipLaunchKernelGGL(minmax_init_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, mm, (long)groups);
     unsigned bx = (unsigned)((ref_per_group + 256 * 8 - 1) / (256 * 8));
     if (bx > 1024) bx = 1024;

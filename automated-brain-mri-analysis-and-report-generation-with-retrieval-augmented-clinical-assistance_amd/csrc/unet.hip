@@ -54,9 +54,8 @@ struct mi355_unet {
     std::vector<TConvWeights> tu;
     std::vector<TConvWeightsH> tuh;
     HeadWeights head;
-    // activation arena: ONE per process and device, shared by every handle (handles run one after
-    // the other on the caller's stream; 5 folds x 2 models would not fit 288 GB with private arenas)
-    char *arena = nullptr;
+    // (the activation arena is not the handle's: one per LANE = per stream the caller launches on, shared by every handle that
+    //  runs on that stream - device_scratch(SCR_ARENA, stream); a forward carries its pointer in its Plan)
     // gaussian importance map cache
     float *gauss_dev = nullptr;
     int gauss_p[3] = {0, 0, 0};
@@ -72,8 +71,6 @@ namespace mi355 {
 
 static std::mutex g_mu;
 static int g_bound_device = -1;
-static struct { void *p; size_t bytes; } g_scratch[SCR_COUNT];
-
 static bool is_gfx950(int dev) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
@@ -102,11 +99,41 @@ int bind_device() {
     return MI355_OK;
 }
 
-int device_scratch(int slot, size_t bytes, void **out, bool zeroed) {
+// Lanes (round 5).  Scratch is per STREAM: the first MAX_LANES distinct streams the caller launches on get a lane of their own -
+// activation arena, aggregation buffers, split-K partials, small reduction scratch - so that independent pieces of the work (the two
+// ensemble members, or two halves of one member's (fold, tile) list: predictor.predict_folds(lanes = 2)) can be in flight on two
+// streams at once: the HBM-bound kernels of one lane (norm passes, transposed convs, first layer, aggregation: a sixth of a
+// config-3 step) then run beside the matrix-bound kernels of the other instead of in front of them.  Work on ONE stream is ordered
+// by that stream, as before.  A stream beyond the table takes over the least recently used lane after a device synchronise.
+// SCR_ZEROS / SCR_ZERO_BIAS are read-only once cleared and shared by all lanes.
+constexpr int MAX_LANES = 4;
+static struct { void *p; size_t bytes; } g_scratch[MAX_LANES][SCR_COUNT];
+static struct { hipStream_t s; bool used; unsigned long tick; } g_lane[MAX_LANES];
+static unsigned long g_lane_tick = 0;
+
+static int lane_of_locked(hipStream_t s, int *lane) {
+    int free_lane = -1, lru = 0;
+    for (int i = 0; i < MAX_LANES; ++i) {
+        if (g_lane[i].used && g_lane[i].s == s) { g_lane[i].tick = ++g_lane_tick; *lane = i; return MI355_OK; }
+        if (!g_lane[i].used && free_lane < 0) free_lane = i;
+        if (g_lane[i].used && g_lane[i].tick < g_lane[lru].tick) lru = i;
+    }
+    if (free_lane < 0) {
+        MI355_HIP(hipDeviceSynchronize());  // whatever still runs on the evicted stream's scratch
+        free_lane = lru;
+    }
+    g_lane[free_lane].s = s; g_lane[free_lane].used = true; g_lane[free_lane].tick = ++g_lane_tick;
+    *lane = free_lane;
+    return MI355_OK;
+}
+
+int device_scratch(int slot, hipStream_t stream, size_t bytes, void **out, bool zeroed) {
     MI355_REQUIRE(slot >= 0 && slot < SCR_COUNT && out, "bad scratch slot %d", slot);
     MI355_TRY(bind_device());
     std::lock_guard<std::mutex> lk(g_mu);
-    auto &b = g_scratch[slot];
+    int lane = 0;
+    if (slot != SCR_ZEROS && slot != SCR_ZERO_BIAS) MI355_TRY(lane_of_locked(stream, &lane));
+    auto &b = g_scratch[lane][slot];
     if (b.bytes < bytes) {
         if (b.p) {
             MI355_HIP(hipDeviceSynchronize());  // work in flight may still use the old buffer
@@ -204,6 +231,7 @@ struct Plan {
     size_t stats_off = 0, scale_off = 0, shift_off = 0, x0_off = 0, total = 0;
     size_t scale2_off = 0, shift2_off = 0;  // second scale / shift pair: a block whose normalisation is applied by its consumer
     size_t stats_bytes = 0;
+    char *arena = nullptr;             // the activation arena of the lane (stream) this forward runs on, set by ensure_arena
 };
 
 static int make_plan(const mi355_unet &net, int N, int D, int H, int W, Plan *pl) {
@@ -239,10 +267,10 @@ static int make_plan(const mi355_unet &net, int N, int D, int H, int W, Plan *pl
     return MI355_OK;
 }
 
-static int ensure_arena(mi355_unet *net, size_t bytes) {
+static int ensure_arena(Plan *pl, hipStream_t s) {
     void *p = nullptr;
-    MI355_TRY(device_scratch(SCR_ARENA, bytes, &p));
-    net->arena = (char *)p;
+    MI355_TRY(device_scratch(SCR_ARENA, s, pl->total, &p));
+    pl->arena = (char *)p;
     return MI355_OK;
 }
 
@@ -279,8 +307,8 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
                      const void *in1, int C1, int N, int Di, int Hi, int Wi, void *out, hipStream_t s,
                      float *head_logits_out = nullptr, bool defer_norm = false, bool in_norm = false) {
     const bool f16 = net->dtype == MI355_F16;
-    double *stats = (double *)(net->arena + pl.stats_off);
-    float *scale = (float *)(net->arena + (defer_norm ? pl.scale2_off : pl.scale_off)), *shift = (float *)(net->arena + (defer_norm ? pl.shift2_off : pl.shift_off));
+    double *stats = (double *)(pl.arena + pl.stats_off);
+    float *scale = (float *)(pl.arena + (defer_norm ? pl.scale2_off : pl.scale_off)), *shift = (float *)(pl.arena + (defer_norm ? pl.shift2_off : pl.shift_off));
     int act = ACT_LRELU;
     double *stats_arg = nullptr;
     if (L.runtime_norm) {
@@ -305,7 +333,7 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
             c.act = act; c.stats = stats_arg;
             if (head_logits_out) { c.head_w = net->head.w_dev; c.head_b = net->head.b_dev; c.head_ncls = net->head.ncls; c.head_out = head_logits_out; }
             if (in_norm) {  // in0 is the previous block's raw conv output: normalise (+ LeakyReLU) while staging
-                c.in_scale = (const float *)(net->arena + pl.scale2_off); c.in_shift = (const float *)(net->arena + pl.shift2_off);
+                c.in_scale = (const float *)(pl.arena + pl.scale2_off); c.in_shift = (const float *)(pl.arena + pl.shift2_off);
                 c.in_act = net->nonlin_first ? ACT_NONE : ACT_LRELU;
             }
             const char *kname = nullptr;
@@ -319,7 +347,7 @@ static int run_block(mi355_unet *net, const Plan &pl, const ConvLayer &L, const 
             c.act = act; c.stats = stats_arg;
             if (head_logits_out) { c.head_w = net->head.w_dev; c.head_b = net->head.b_dev; c.head_ncls = net->head.ncls; c.head_out = head_logits_out; }
             if (in_norm) {  // in0 is the previous block's raw conv output: the F(2x2x2,3x3x3) kernel normalises (+ LeakyReLU) its brick in LDS
-                c.in_scale = (const float *)(net->arena + pl.scale2_off); c.in_shift = (const float *)(net->arena + pl.shift2_off);
+                c.in_scale = (const float *)(pl.arena + pl.scale2_off); c.in_shift = (const float *)(pl.arena + pl.shift2_off);
                 c.in_act = net->nonlin_first ? ACT_NONE : ACT_LRELU;
             }
             const char *kname = nullptr;
@@ -377,8 +405,8 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
                             FeatNorm *head_norm = nullptr) {
     const int np = net->num_pool;
     const bool f16 = net->dtype == MI355_F16;
-    auto buf = [&](int k, int l) { return (void *)(net->arena + pl.off[k][l]); };
-    const void *cur = (const void *)(net->arena + pl.x0_off);
+    auto buf = [&](int k, int l) { return (void *)(pl.arena + pl.off[k][l]); };
+    const void *cur = (const void *)(pl.arena + pl.x0_off);
     int curC = net->cin_pad;
     std::vector<const void *> skip(np);
     std::vector<int> skipC(np);
@@ -446,8 +474,8 @@ static int forward_features(mi355_unet *net, const Plan &pl, int N, int D, int H
             const bool defer = to_head || (i + 1 < net->dec[u].size() && can_defer_norm(net, L, net->dec[u][i + 1], N, Dl, Hl, Wl));
             MI355_TRY(run_block(net, pl, L, in0, C0, in1, C1, N, Dl, Hl, Wl, out, s, nullptr, defer, pending_d));
             if (to_head) {
-                head_norm->scale = (const float *)(net->arena + pl.scale2_off);
-                head_norm->shift = (const float *)(net->arena + pl.shift2_off);
+                head_norm->scale = (const float *)(pl.arena + pl.scale2_off);
+                head_norm->shift = (const float *)(pl.arena + pl.shift2_off);
                 head_norm->slope = net->nonlin_first ? 1.0f : net->slope;  // ConvDropoutNonlinNorm: the activation came before the norm
             }
             pending_d = defer;
@@ -511,6 +539,7 @@ static void gaussian_map(const int p[3], double sigma_scale, std::vector<float> 
 }
 
 static int ensure_gaussian(mi355_unet *net, const int p[3]) {
+    std::lock_guard<std::mutex> lk(g_mu);  // (one handle may be driven from two lanes)
     if (net->gauss_dev && net->gauss_p[0] == p[0] && net->gauss_p[1] == p[1] && net->gauss_p[2] == p[2])
         return MI355_OK;
     if (net->gauss_dev) { MI355_HIP(hipDeviceSynchronize()); MI355_HIP(hipFree(net->gauss_dev)); net->gauss_dev = nullptr; }
@@ -568,7 +597,7 @@ static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X,
     MI355_REQUIRE(nm <= 64, "too many mirrors");
     Plan pl;
     MI355_TRY(make_plan(*net, bt * nm, g.P[0], g.P[1], g.P[2], &pl));
-    MI355_TRY(ensure_arena(net, pl.total));
+    MI355_TRY(ensure_arena(&pl, s));
     if (mine.empty()) return MI355_OK;
     for (size_t b0 = 0; b0 < mine.size(); b0 += bt) {
         const int nb = (int)std::min<size_t>(bt, mine.size() - b0);
@@ -584,7 +613,7 @@ static int sw_accumulate(mi355_unet *net, const float *vol, int Z, int Y, int X,
         ProfScope ps(net, s, "extract_tiles_kernel", 0.0, pv * (4.0 * net->in_channels + (net->dtype == MI355_F16 ? 2.0 : 4.0) * net->cin_pad));
         MI355_TRY(extract_tiles(vol, net->in_channels, Z, Y, X, g.pad_lo[0], g.pad_lo[1], g.pad_lo[2], samples.data(),
                                 (int)samples.size(), g.P[0], g.P[1], g.P[2], net->cin_pad,
-                                (void *)(net->arena + pl.x0_off), net->dtype, s));
+                                (void *)(pl.arena + pl.x0_off), net->dtype, s));
         }
         const void *feat; int fc; bool is_logits = false;
         FeatNorm head_norm;
@@ -722,9 +751,9 @@ extern "C" int mi355_unet_forward(mi355_unet_t net, const float *x_dev, int n, i
     hipStream_t s = (hipStream_t)stream;
     Plan pl;
     MI355_TRY(make_plan(*net, n, d, h, w, &pl));
-    MI355_TRY(ensure_arena(net, pl.total));
+    MI355_TRY(ensure_arena(&pl, s));
     const int64_t V = (int64_t)d * h * w;
-    MI355_TRY(nchw_to_ndhwc(x_dev, n, net->in_channels, V, net->cin_pad, (void *)(net->arena + pl.x0_off), net->dtype, s));
+    MI355_TRY(nchw_to_ndhwc(x_dev, n, net->in_channels, V, net->cin_pad, (void *)(pl.arena + pl.x0_off), net->dtype, s));
     const void *feat; int fc; bool is_logits = false;
     FeatNorm head_norm;
     MI355_TRY(forward_features(net, pl, n, d, h, w, &feat, &fc, s, &is_logits, logits_dev, &head_norm));
@@ -846,7 +875,7 @@ extern "C" int mi355_sw_predict(const mi355_unet_t *nets, int n_nets, const floa
     // aggregation scratch: process-wide like the activation arena, grown on demand, never freed per call - a
     // hipMalloc / synchronise / hipFree round trip per volume costs more than the small kernels of a step
     void *scratch = nullptr;
-    MI355_TRY(device_scratch(SCR_SW_AGG, ZYXp * (size_t)(C + 1) * sizeof(float), &scratch));
+    MI355_TRY(device_scratch(SCR_SW_AGG, s, ZYXp * (size_t)(C + 1) * sizeof(float), &scratch));
     float *agg = (float *)scratch, *cnt = agg + ZYXp * C;
     int rc = MI355_OK;
     for (int f = 0; f < n_nets && rc == MI355_OK; ++f) {

@@ -47,10 +47,59 @@ def _to_device(data, device):
     return data.contiguous()
 
 
+_LANE_STREAMS = {}   # device index -> the side streams of predict_folds(lanes > 1): created once, the library keeps a lane of scratch per stream
+
+
+def default_lanes() -> int:
+    """MI355_LANES (default 2): how many HIP streams one ``predict_folds`` call spreads its (fold, tile) work list over."""
+    import os
+    try:
+        return max(1, min(4, int(os.environ.get("MI355_LANES", "2"))))
+    except ValueError:
+        return 2
+
+
+def _lane_streams(device, n):
+    import torch
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    have = _LANE_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=key))
+    return have[:n]
+
+
+def _predict_folds_lanes(nets, data, lanes, patch_size, step_size, do_mirroring, mirror_axes, use_gaussian, nonlin, batch_tiles):
+    """``predict_folds`` over ``lanes`` HIP streams of ONE GPU: the (fold, tile) work list is dealt round-robin over the lanes exactly
+    as ``mi355_sw_partial_folds`` deals it over the ranks of SURVEY.md 8e partitioning B; every lane accumulates its items into an
+    aggregate of its own on a stream of its own (the library keeps an activation arena per stream), the aggregates are added in
+    lane order and normalised once.  Why: a sixth of a TTA step is HBM-bound kernels (norm passes, transposed convs, first layer,
+    aggregation) that leave the matrix cores idle, and the deep levels' launches do not fill the chip; with two lanes in flight
+    the hardware runs one lane's memory-bound kernels beside the other's matrix-bound ones."""
+    import torch
+    cur = torch.cuda.current_stream(data.device)
+    ready = cur.record_event()
+    parts = []
+    for r, st in enumerate(_lane_streams(data.device, lanes)):
+        st.wait_event(ready)
+        with torch.cuda.stream(st):
+            agg, cnt = predict_tile_sharded(list(nets), data, r, lanes, patch_size, step_size, do_mirroring, mirror_axes, use_gaussian,
+                                            nonlin, batch_tiles, data.device, want_cnt=(r == 0))
+        for t in (agg, cnt):
+            if t is not None:
+                t.record_stream(cur)   # (allocated on the lane's stream, consumed on the caller's)
+        parts.append((agg, cnt))
+        cur.wait_stream(st)
+    total = parts[0][0]
+    for agg, _ in parts[1:]:
+        total += agg   # lane order: deterministic
+    return finish_sharded(total, parts[0][1], tuple(data.shape[1:]), patch_size, len(nets))
+
+
 def predict_folds(nets: Sequence[UNet], data, patch_size=(128, 128, 128), step_size=0.5, do_mirroring=True,
-                  mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid", batch_tiles=0, device="cuda"):
+                  mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid", batch_tiles=0, device="cuda", lanes=None):
     """Class probabilities ``[K, Z, Y, X]`` (CUDA fp32) of one preprocessed ``[C, Z, Y, X]`` volume,
-    averaged over ``nets`` (the fold ensemble of driver :95-128)."""
+    averaged over ``nets`` (the fold ensemble of driver :95-128).  ``lanes`` (default ``MI355_LANES``, 2): number of HIP streams
+    the work list is spread over when it has at least that many (fold, tile) items; 1 = one ``mi355_sw_predict`` call."""
     import torch
     if len(nets) == 0:
         raise ValueError("no networks given")
@@ -58,6 +107,14 @@ def predict_folds(nets: Sequence[UNet], data, patch_size=(128, 128, 128), step_s
     if data.dim() != 4 or data.shape[0] != nets[0].topology.in_channels:
         raise ValueError(f"data must be [C={nets[0].topology.in_channels}, Z, Y, X]")
     _, z, y, x = data.shape
+    lanes = default_lanes() if lanes is None else int(lanes)
+    if lanes > 1:
+        from . import ops
+        n_items = len(nets) * int(np.prod([len(ops.compute_steps(int(p), max(int(p), int(d)), float(step_size)))
+                                           for p, d in zip(patch_size, (z, y, x))]))
+        # (every lane needs at least one full forward batch for the split to pay: 2 items per lane)
+        if n_items >= 2 * lanes:
+            return _predict_folds_lanes(nets, data, lanes, patch_size, step_size, do_mirroring, mirror_axes, use_gaussian, nonlin, batch_tiles)
     k = nets[0].topology.num_classes
     probs = torch.empty((k, z, y, x), dtype=torch.float32, device=data.device)
     opts = _opts(patch_size, step_size, use_gaussian, do_mirroring, mirror_axes, nonlin, batch_tiles)
@@ -87,7 +144,7 @@ def predict_preprocessed_data_return_seg_and_softmax(net: UNet, data, do_mirrori
 
 def predict_tile_sharded(net, data, rank: int, world: int, patch_size=(128, 128, 128), step_size=0.5,
                          do_mirroring=True, mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid",
-                         batch_tiles=0, device="cuda"):
+                         batch_tiles=0, device="cuda", want_cnt=True):
     """This rank's share of one volume: returns (agg [K,Zp,Yp,Xp], cnt [Zp,Yp,Xp]); ``finish_sharded`` turns the
     rank-ordered sum into probabilities.  ``net`` is one network (tiles with index % world == rank) or the FOLD LIST of
     one ensemble member (driver :161, :112-128): then the work list is (fold, tile), item ``f * tiles + t`` goes to rank
@@ -101,12 +158,12 @@ def predict_tile_sharded(net, data, rank: int, world: int, patch_size=(128, 128,
     zp, yp, xp = (max(z, patch_size[0]), max(y, patch_size[1]), max(x, patch_size[2]))
     k = nets[0].topology.num_classes
     agg = torch.empty((k, zp, yp, xp), dtype=torch.float32, device=data.device)
-    cnt = torch.empty((zp, yp, xp), dtype=torch.float32, device=data.device)
+    cnt = torch.empty((zp, yp, xp), dtype=torch.float32, device=data.device) if want_cnt else None   # (the normaliser is the same on every rank)
     opts = _opts(patch_size, step_size, use_gaussian, do_mirroring, mirror_axes, nonlin, batch_tiles)
     handles = (C.c_void_p * len(nets))(*[n.handle for n in nets])
     stream = torch.cuda.current_stream(data.device).cuda_stream
     _lib.check(_lib.load().mi355_sw_partial_folds(handles, len(nets), data.data_ptr(), z, y, x, C.byref(opts), rank, world,
-                                                  agg.data_ptr(), cnt.data_ptr(), stream), "mi355_sw_partial_folds")
+                                                  agg.data_ptr(), cnt.data_ptr() if want_cnt else None, stream), "mi355_sw_partial_folds")
     return agg, cnt
 
 

@@ -82,6 +82,7 @@ def parse_args(argv=None):
                     help="config 3 with N > 1: 'cases' = one volume per rank per step (weak scaling, no data-path collective); 'tiles' = "
                          "ONE volume per step for all ranks, its (fold, tile) work list dealt over the ranks and one RCCL all_gather of "
                          "the partial aggregates per ensemble member (SURVEY.md 8e partitioning B, strong scaling)")
+    ap.add_argument("--lanes", type=int, default=0, help="HIP streams one predict_folds call spreads its (fold, tile) list over (0: the product's default, MI355_LANES or 2)")
     ap.add_argument("--folds", type=int, default=1, help="folds per ensemble member (the reference runs 5: driver :161)")
     ap.add_argument("--dtype", choices=("f32", "f16"), default=None, help="default: f32 for config 2, f16 for configs 3 and 4")
     # rehearsal of the N > 1 launch path on a box with fewer GPUs than ranks: ranks share device 0 and synchronise
@@ -200,18 +201,34 @@ def committed_counter(fname, section, kernel, field):
 
 def timed_region(ctx, step, steps, warmup, nets):
     """W untimed steps, then exactly K steps between two barrier + synchronize brackets; per-kernel HIP-event
-    profile of the timed steps (events recorded by the library on the launch stream)."""
+    profile (events recorded by the library on the launch stream) of the timed steps - or, when the step runs on more than one
+    lane (predictor.predict_folds(lanes > 1): kernels of two streams overlap, so an event pair around one of them also times its
+    neighbours), of ONE extra, untimed step on a single lane after the timed region."""
+    from brats_amd import predictor
+    lanes = predictor.default_lanes()
     out = None
     for _ in range(warmup):
         out = step()
-    for net in nets:
-        net.profile(True)
+    if lanes == 1:
+        for net in nets:
+            net.profile(True)
     ctx.sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
     ctx.sync_all()
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    if lanes > 1:
+        os.environ["MI355_LANES"] = "1"
+        try:
+            step()   # (arena of the caller's stream grows here, outside any timed region)
+            for net in nets:
+                net.profile(True)
+            ctx.sync_all()
+            step()
+            ctx.sync_all()
+        finally:
+            os.environ["MI355_LANES"] = str(lanes)
     prof = {}
     for net in nets:
         for e in net.read_profile():
@@ -395,6 +412,7 @@ def run_single_volume(ctx, args, config, dtype, steps, warmup, data, props, step
                config={"workload": wl["name"] + (f" [{folds} folds per member]" if folds != 1 else ""), "patch": list(PATCH),
                        "tiles_per_volume": n_tiles, "mirrors": n_mirrors, "folds_per_member": folds,
                        "models": [m[0] for m in wl["models"]], "crop": list(data.shape[1:]),
+                       "lanes": (1 if tiles_mode else predictor.default_lanes()),   # HIP streams per predict_folds call (predictor.py)
                        "sharding": ("tiles: ONE volume per step, the (fold, tile) work list of each ensemble member dealt round-robin over the "
                                     "ranks, one RCCL all_gather of the partial aggregates per member, rank-ordered sum (SURVEY.md 8e B)")
                                    if tiles_mode else "cases (one volume per rank per step)",
@@ -562,6 +580,8 @@ def run_config4(ctx, args, dtype):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.lanes > 0:
+        os.environ["MI355_LANES"] = str(args.lanes)   # (before the self-launch: the ranks inherit it)
     maybe_self_launch(args, argv)
 
     import torch  # noqa: F401  (first GPU-capable import happens only here, after the self-launch decision)
