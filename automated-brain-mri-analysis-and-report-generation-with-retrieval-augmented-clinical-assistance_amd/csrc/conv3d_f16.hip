@@ -704,45 +704,41 @@ __device__ unsigned long long h16_stamps[1024 * 16];
 #define H16_T(v)
 #define H16_ACC(k, a, b)
 #endif
-template <int EVERY_>
+template <int EVERY_, int NF_ = 2>
 struct DmaGeomH {
     static constexpr int IX = 10, IY = 10, IZ = 10, BV = IX * IY * IZ;
     static constexpr int PLANE_SLOTS = 1024, PLANE_BYTES = PLANE_SLOTS * 16, BUF_BYTES = 2 * PLANE_BYTES;
-#ifndef MI355_H16_INTERLEAVED
-#define MI355_H16_INTERLEAVED 0
-#endif
-    // Brick layout in LDS.  Round 3: planar [8-channel half][voxel][16 B] - with channel-blocked activations (common.h) the 64
-    // lanes of a piece fetch 64 consecutive brick voxels of ONE block, i.e. rows of 10 x 16 contiguous bytes, and the
-    // fragment reads (lane = voxel, stride 16 B) are conflict-free.  (Round 2, plain NDHWC: interleaved [voxel][half][16 B] so
-    // that two adjacent lanes fetched the 32 contiguous bytes of a voxel - 32 lines per instruction instead of 64 - at the
-    // price of 2-way bank conflicts on every fragment read; MI355_H16_INTERLEAVED=1 still builds it: adjacent lanes then
-    // fetch from two blocks.)
-    static constexpr bool INTERLEAVED = MI355_H16_INTERLEAVED != 0;
-    static constexpr int VOX_BYTES = INTERLEAVED ? 32 : 16;
+    // Brick layout in LDS: planar [8-channel half][voxel][16 B] (round 3) - with channel-blocked activations (common.h) the 64
+    // lanes of a piece fetch 64 consecutive brick voxels of ONE block, i.e. rows of 10 x 16 contiguous bytes, and the fragment
+    // reads (lane = voxel, stride 16 B) are conflict-free.  (Round 2's interleaved [voxel][half][16 B] brick for plain NDHWC
+    // tensors went in round 5 together with the LDS transposition image of the epilogue: neither had a user left.)
+    static constexpr bool INTERLEAVED = false;
+    static constexpr int VOX_BYTES = 16;
+    static constexpr int NF = NF_;  // 32-cout fragments per wave: 2 = conv3_f16_dma_kernel (64 couts per workgroup), 1 = conv3_f16_c32_kernel
     static constexpr int D = 9;    // weight ring depth in taps (divides 27: the ring phase is the same in every chunk)
     static constexpr int KD = 8;   // DMAs per wave and chunk: range wave + 4 (k & 3) of plane k >> 2
     static constexpr int EVERY = EVERY_;  // DMA k goes out in tap EVERY * k: four waves issuing 64-line DMAs in the same tap ask the
                                           // L1 for more lines than a tap has cycles (stamps: +1.3-2.2k cycles per chunk at EVERY = 1)
     static constexpr bool dma_tap(int t) { return t % EVERY == 0 && t / EVERY < KD; }
-    // loads issued after the weight loads of tap t (which went out at the end of tap t - D): two per tap of taps t-8 .. t-1
+    // loads issued after the weight loads of tap t (which went out at the end of tap t - D): NF per tap of taps t-8 .. t-1
     // and the DMAs among those taps (taps < 0 are the previous chunk's)
     static constexpr int pending(int t) {
-        int n = 2 * (D - 1);
+        int n = NF * (D - 1);
         for (int j = t - (D - 1); j <= t - 1; ++j) n += dma_tap((j + 27) % 27) ? 1 : 0;
         return n;
     }
     // weight loads issued after the chunk's last DMA
-    static constexpr int after_last_dma = 2 * (27 - EVERY * (KD - 1));
-    // epilogue: each wave transposes its 128 voxels x 64 couts through a private LDS image (row = voxel, 144-B pitch: the
-    // 8-B writes of 32 consecutive voxels spread over all banks) and stores whole 128-B lines
-    static constexpr int EPI_PITCH = 144, EPI_WAVE_BYTES = 128 * EPI_PITCH;
-    static constexpr int RED_OFF = 2 * BUF_BYTES, BIAS_OFF = RED_OFF + 4 * 64 * 2 * 4, EPI_OFF = BIAS_OFF + 64 * 4;
-    // INAFF: a 1-KiB junk area (the write target of out-of-volume pieces) and the fp16 scale / shift tables [N][C0]
-    static constexpr int JUNK_OFF = EPI_OFF + 4 * EPI_WAVE_BYTES, TAB_OFF = JUNK_OFF + 1024;
+    static constexpr int after_last_dma = NF * (27 - EVERY * (KD - 1));
+    // LDS: two brick buffers, the bias of the workgroup's couts, and for INAFF a 1-KiB junk area (the write target of
+    // out-of-volume pieces) and the fp16 scale / shift tables [N][C0].  (Round 5: the 72-KiB transposition image of round 2's
+    // epilogue is gone - the launch asked for 140 KiB of which it used 66, which kept every kernel that needs LDS off the CU
+    // while this one ran, and capped the tables at 19 KiB: the 256- and 512-channel levels fell back to the register-staged kernel.)
+    static constexpr int BIAS_OFF = 2 * BUF_BYTES, JUNK_OFF = BIAS_OFF + 64 * 4, TAB_OFF = JUNK_OFF + 1024;
     static constexpr size_t LDS_BYTES = (size_t)JUNK_OFF;
-    static constexpr int TAB_MAX_BYTES = 160 * 1024 - TAB_OFF;
+    static constexpr int WG_PER_CU = NF == 1 ? 2 : 1;   // (NF = 1: 64 accumulators per wave, two waves per SIMD)
+    static constexpr int TAB_MAX_BYTES = 160 * 1024 / WG_PER_CU - TAB_OFF;
     // INAFF: piece k (DMA in tap EVERY k) has landed once the weights of tap EVERY k + 10 have been waited for (they were
-    // issued after it); it is read back in that tap and normalised + written in the next one
+    // issued after it); it is read back in that tap and normalised + written in the next one (NF = 1: in the next two)
     static constexpr int aff_read_tap(int k) { return EVERY * k + 10; }
 };
 
@@ -751,17 +747,21 @@ struct DmaGeomH {
 // waits guarantee they have landed): ds_read_b128, 12 packed fp16 ops, ds_write_b128, dealt out over the taps.  Out-of-volume
 // pieces (zeros from the zero page; padding follows the norm) are written to a junk area instead.  Same arithmetic as the
 // pipelined kernel's INAFF path: scale and shift as fp16, one fused multiply-add, max(y, slope y).
-template <bool STATS, bool INAFF = false>
-__global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
+template <bool STATS, bool INAFF, int NF, bool HEAD>
+__device__ __forceinline__ void conv3_f16_dma_body(const ConvArgsH &p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    typedef DmaGeomH<INAFF ? 2 : 3> G;
-    static_assert(!INAFF || G::aff_read_tap(G::KD - 1) + 1 <= 26, "the last piece must be normalised within its chunk");
-    constexpr int MF = 4, NF = 2;
+    typedef DmaGeomH<INAFF ? 2 : 3, NF> G;
+    static_assert(NF == 1 || NF == 2, "one or two 32-cout fragments per wave");
+    static_assert(!HEAD || (NF == 1 && !STATS && !INAFF), "the fused head is built for the Cout = 32, BatchNorm-folded last conv only");
+    // INAFF: the last piece must be normalised within its chunk (NF = 2: read in tap aff_read_tap, finished in the next one;
+    // NF = 1 has two MFMA gaps per tap to spare, so a piece takes the next TWO taps)
+    static_assert(!INAFF || G::aff_read_tap(G::KD - 1) + (NF == 1 ? 2 : 1) <= 26, "the last piece must be normalised within its chunk");
+    constexpr int MF = 4;
     constexpr int IX = G::IX, IY = G::IY;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *bias_lds = (float *)(lds_raw + G::BIAS_OFF);
-    if (tid < 64) bias_lds[tid] = p.bias[(int)blockIdx.y * NF * 32 + tid];  // (published by the prologue's barrier)
+    if (tid < NF * 32) bias_lds[tid] = p.bias[(int)blockIdx.y * NF * 32 + tid];  // (published by the prologue's barrier)
     const int tab_n = p.N * p.C0;  // INAFF: fp16 scale [N][C0], then shift [N][C0]
     if constexpr (INAFF) {
         half_t *tab = (half_t *)(lds_raw + G::TAB_OFF);
@@ -796,44 +796,35 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
 
     // tile-invariant lane part of the four DMA ranges of a plane: voxel offset from the brick origin (24 bits) | the
     // brick faces the voxel lies on << 24 (bit 6: a padding slot beyond the brick)
-    constexpr int NPK = G::INTERLEAVED ? 8 : 4;  // interleaved: DMA k covers voxels 32 (wave + 4 k) .. + 31, two lanes each
-    unsigned dma_pk[NPK];
+    unsigned dma_pk[4];
 #pragma unroll
-    for (int k = 0; k < NPK; ++k) {
-        const int bv = G::INTERLEAVED ? (wave + 4 * k) * 32 + (lane >> 1) : (wave + 4 * k) * 64 + lane;
+    for (int k = 0; k < 4; ++k) {
+        const int bv = (wave + 4 * k) * 64 + lane;
         const int bz = bv / (IX * IY), rr = bv - bz * (IX * IY), by = rr / IX, bx = rr - by * IX;
         const int face = (bz == 0) | ((bz == G::IZ - 1) << 1) | ((by == 0) << 2) | ((by == IY - 1) << 3) | ((bx == 0) << 4) | ((bx == IX - 1) << 5);
         dma_pk[k] = bv < G::BV ? (unsigned)(((bz * p.Hi + by) * p.Wi + bx) | (face << 24)) : (64u << 24);
     }
-    const unsigned lane_half16 = (lane & 1) * 16;  // (interleaved brick: the lane's half within a voxel's 32 B of LDS / of the tables)
-    const unsigned lane_half1 = (unsigned)(lane & 1) * (unsigned)((long)p.Di * p.Hi * p.Wi * 16);  // ... and its block in global memory
     auto dma = [&](const TileCoord &tc, int faces, int ch, auto k_c, char *buf) {
         constexpr int k = decltype(k_c)::value;
         const int cglob = ch * 16;
         const half_t *src; int Csrc, coff;
         if (cglob < p.C0) { src = p.in0; Csrc = p.C0; coff = cglob; }
         else { src = p.in1; Csrc = p.C1; coff = cglob - p.C0; }
-        // wave-uniform part (SALU): block coff / 8 (+ the piece's half in the planar layout) of sample n, at the brick origin
-        // voxel, which may lie one voxel outside the tensor
+        // wave-uniform part (SALU): block coff / 8 + the piece's half of sample n, at the brick origin voxel, which may lie one
+        // voxel outside the tensor
         const long Vi = (long)p.Di * p.Hi * p.Wi;
-        src += (((long)tc.n * (Csrc >> 3) + (coff >> 3) + (G::INTERLEAVED ? 0 : (k >> 2))) * Vi + ((long)(tc.oz0 - 1) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1)) * 8;
-        unsigned pk = dma_pk[G::INTERLEAVED ? k : (k & 3)];
+        src += (((long)tc.n * (Csrc >> 3) + (coff >> 3) + (k >> 2)) * Vi + ((long)(tc.oz0 - 1) * p.Hi + (tc.oy0 - 1)) * p.Wi + (tc.ox0 - 1)) * 8;
+        unsigned pk = dma_pk[k & 3];
         asm volatile("" : "+v"(pk));
         bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
         unsigned off = (pk & 0xffffffu) << 4;  // bytes: 16 per voxel of a block (< 2^32: host check)
-        if constexpr (G::INTERLEAVED) off += lane_half1;                  // odd lanes: the next block (channels 8..15) of the same voxel
         const char *gin = (const char *)src + off;
         asm volatile("" : "+v"(gin));  // (computed for every lane: left to itself the compiler branches around it, and a basic-block
                                        //  boundary between the MFMAs of a tap makes it wait for every outstanding LDS read there)
         const char *g = inside ? gin : (const char *)p.zeros;  // the zero page holds both planes' pieces
         asm volatile("" : "+v"(g));
-        if constexpr (G::INTERLEAVED) {
-            char *dst = buf + (wave + 4 * k) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        } else {
-            char *dst = buf + (k >> 2) * G::PLANE_BYTES + (wave + 4 * (k & 3)) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        }
+        char *dst = buf + (k >> 2) * G::PLANE_BYTES + (wave + 4 * (k & 3)) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
 
     // INAFF: this lane's piece k of a brick buffer, read back / normalised and written in place (see above the kernel)
@@ -845,26 +836,25 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     auto aff_bases = [&](char *buf, const TileCoord &tc, int ch, unsigned &pb, unsigned &ta, unsigned &tb) {
         pb = (unsigned)(size_t)(lds_char_t *)buf + wave * 1024 + lane * 16;
         ta = (unsigned)(size_t)(lds_char_t *)(lds_raw + G::TAB_OFF) + (tc.n * p.C0 + ch * 16) * 2;
-        if constexpr (G::INTERLEAVED) ta += lane_half16;  // (odd lanes hold channels 8..15)
         tb = ta + tab_n * 2;
         asm volatile("" : "+v"(pb), "+v"(ta), "+v"(tb));
     };
     auto aff_read = [&](unsigned pb, auto k_c) {
         constexpr int k = decltype(k_c)::value;
-        return *(const __attribute__((address_space(3))) f32x4 *)(pb + (G::INTERLEAVED ? 4 * k * 1024 : (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024));
+        return *(const __attribute__((address_space(3))) f32x4 *)(pb + ((k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024));
     };
     auto aff_apply = [&](int faces, auto k_c, unsigned pb, unsigned ta, unsigned tb, f32x4 raw) {
         constexpr int k = decltype(k_c)::value;
-        const f16x8 sc = *(const __attribute__((address_space(3))) f16x8 *)(ta + (G::INTERLEAVED ? 0 : (k >> 2) * 16));
-        const f16x8 sh = *(const __attribute__((address_space(3))) f16x8 *)(tb + (G::INTERLEAVED ? 0 : (k >> 2) * 16));
+        const f16x8 sc = *(const __attribute__((address_space(3))) f16x8 *)(ta + (k >> 2) * 16);
+        const f16x8 sh = *(const __attribute__((address_space(3))) f16x8 *)(tb + (k >> 2) * 16);
         f16x8 y = __builtin_elementwise_fma(__builtin_bit_cast(f16x8, raw), sc, sh);
         const f16x8 sl8 = {slope_in, slope_in, slope_in, slope_in, slope_in, slope_in, slope_in, slope_in};
         y = __builtin_elementwise_max(y, y * sl8);
-        unsigned pk = dma_pk[G::INTERLEAVED ? k : (k & 3)];
+        unsigned pk = dma_pk[k & 3];
         asm volatile("" : "+v"(pk));
         const bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
         // (padding follows the norm: out-of-volume pieces stay the zeros the DMA wrote; their result goes to the junk area)
-        unsigned dst = inside ? pb + (G::INTERLEAVED ? 4 * k * 1024 : (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024) : aff_junk;
+        unsigned dst = inside ? pb + ((k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024) : aff_junk;
         asm volatile("" : "+v"(dst));
         *(__attribute__((address_space(3))) f32x4 *)dst = __builtin_bit_cast(f32x4, y);
     };
@@ -873,13 +863,15 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     // MFMA it cost 17 % of the kernel (conv3_f16_dma_kernel<true, true> 1010 against 1215 TFLOP/s without it): a gap hides about
     // six VALU instructions (MI355X_MICROARCH.md, vector-instruction issue cost) and the block had 17 plus a ds_write, and the
     // scale / shift rows were read from LDS in the gap that used them, i.e. with their full latency exposed.  Now: tap t reads
-    // the piece AND its scale / shift rows (stage 0); tap t + 1 does fma | mul | max | select + write behind MFMAs 2, 3, 4, 5.
+    // the piece AND its scale / shift rows (stage 0); NF = 2: tap t + 1 does fma | mul | max | select + write behind MFMAs 2, 3, 4,
+    // 5; NF = 1 (four MFMAs per tap): fma | mul behind MFMAs 2, 3 of tap t + 1, max | select + write behind those of tap t + 2 -
+    // stage 0 of the NEXT piece (tap t + 2, before MFMA 2) only overwrites raw / sc / sh, which stages 3, 4 no longer read.
     struct AffStage { f32x4 raw; f16x8 sc, sh, y, ys; };
     auto aff_s0 = [&](AffStage &st, unsigned pb, unsigned ta, unsigned tb, auto k_c) {
         constexpr int k = decltype(k_c)::value;
         st.raw = aff_read(pb, k_c);
-        st.sc = *(const __attribute__((address_space(3))) f16x8 *)(ta + (G::INTERLEAVED ? 0 : (k >> 2) * 16));
-        st.sh = *(const __attribute__((address_space(3))) f16x8 *)(tb + (G::INTERLEAVED ? 0 : (k >> 2) * 16));
+        st.sc = *(const __attribute__((address_space(3))) f16x8 *)(ta + (k >> 2) * 16);
+        st.sh = *(const __attribute__((address_space(3))) f16x8 *)(tb + (k >> 2) * 16);
     };
     auto aff_s1 = [&](AffStage &st) { st.y = __builtin_elementwise_fma(__builtin_bit_cast(f16x8, st.raw), st.sc, st.sh); };
     auto aff_s2 = [&](AffStage &st) {
@@ -889,10 +881,10 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     auto aff_s3 = [&](AffStage &st) { st.y = __builtin_elementwise_max(st.y, st.ys); };
     auto aff_s4 = [&](AffStage &st, int faces, unsigned pb, auto k_c) {
         constexpr int k = decltype(k_c)::value;
-        unsigned pk = dma_pk[G::INTERLEAVED ? k : (k & 3)];
+        unsigned pk = dma_pk[k & 3];
         asm volatile("" : "+v"(pk));
         const bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
-        unsigned dst = inside ? pb + (G::INTERLEAVED ? 4 * k * 1024 : (k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024) : aff_junk;
+        unsigned dst = inside ? pb + ((k >> 2) * G::PLANE_BYTES + 4 * (k & 3) * 1024) : aff_junk;
         asm volatile("" : "+v"(dst));
         *(__attribute__((address_space(3))) f32x4 *)dst = __builtin_bit_cast(f32x4, st.y);
     };
@@ -903,14 +895,35 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         const int v = (wave * MF + mf) * 32 + l31;
-        a_base[mf] = G::INTERLEAVED ? (((v >> 6) * IY + ((v >> 3) & 7)) * IX + (v & 7)) * 32 + half * 16
-                                    : half * G::PLANE_BYTES + (((v >> 6) * IY + ((v >> 3) & 7)) * IX + (v & 7)) * 16;
+        a_base[mf] = half * G::PLANE_BYTES + (((v >> 6) * IY + ((v >> 3) & 7)) * IX + (v & 7)) * 16;
     }
     const int co_blk = (int)blockIdx.y * NF * 32;
     const char *wblk = (const char *)(p.wp + (size_t)blockIdx.y * p.nchunks * (27 * NF * 512));
     const unsigned wlane = lane * 16;
 #define H16_WLOAD(DST, SBASE, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(DST) : "v"(wl), "s"(SBASE), "n"(IMM) : "memory")
-#define H16_WWAIT(W, N) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(W[0]), "+v"(W[1]) : "n"(N) : "memory")
+    // (the ring registers are operands of the wait: the compiler must not read or move them before it)
+    auto wwait = [&](auto &w, auto n_c) {
+        constexpr int N = decltype(n_c)::value;
+        if constexpr (NF == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[0]) : "n"(N) : "memory");
+    };
+    typedef std::integral_constant<int, 0> Zero;
+
+    // HEAD: the fused 1x1x1 head's weights as MFMA A operands (hi + lo fp16 halves, conv_epilogue_f16), kernel invariants
+    f16x8 wh[2][2];
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = sl * 8 + j;
+                const int co = co_blk + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float w = l31 < p.head_ncls ? p.head_w[l31 * p.Cout + co] : 0.f;
+                const half_t hi_h = (half_t)w;
+                wh[sl][0][j] = hi_h;
+                wh[sl][1][j] = (half_t)(w - (float)hi_h);
+            }
+    }
 
 #ifdef MI355_H16_STAMPS
     const bool stamp_on = tid == 0 && blockIdx.y == 0;
@@ -928,10 +941,9 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
             const unsigned wl = wlane;  // (asm operands alone do not capture)
             auto &w = wq[t];
             H16_WLOAD(w[0], wb, 0);
-            H16_WLOAD(w[1], wb, 1024);
+            if constexpr (NF == 2) H16_WLOAD(w[1], wb, 1024);
         });
-        // (the ring registers are operands of the wait: the compiler must not read or move them before it)
-        static_for<0, G::D>([&](auto t_c) { auto &w = wq[decltype(t_c)::value]; H16_WWAIT(w, 0); });
+        static_for<0, G::D>([&](auto t_c) { wwait(wq[decltype(t_c)::value], Zero{}); });
         if constexpr (INAFF) {
             __syncthreads();  // the tables
             unsigned pb, ta, tb;
@@ -1004,19 +1016,20 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
             static_for<0, 27>([&](auto tap_c) {
                 constexpr int tap = decltype(tap_c)::value;
                 constexpr int slot = tap % G::D;
-                constexpr int pending = G::pending(tap);
                 auto &wc = wq[slot];
-                H16_WWAIT(wc, pending);
+                wwait(wc, std::integral_constant<int, G::pending(tap)>{});
                 // the first MFMAs go out before the tap's memory instructions: the compiler waits for ALL outstanding LDS
                 // reads before the first MFMA of a tap (lgkmcnt(0): it will not count past an LDS-DMA), so the reads of tap
                 // t+1 are issued behind two MFMAs of tap t and are a tap old when that wait comes
-                static_for<0, 8>([&](auto i_c) {
+                static_for<0, MF * NF>([&](auto i_c) {
                     constexpr int i = decltype(i_c)::value;
-                    constexpr int mf = i >> 1, nf = i & 1;
+                    constexpr int mf = i / NF, nf = i % NF;
                     acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[slot][nf], a[tap & 1][mf], acc[mf][nf], 0, 0, 0);
-                    // INAFF: piece ta / EVERY (read a tap ago) is normalised in this tap, one stage per MFMA gap
-                    constexpr int ta = tap - 11, tr = tap - 10;
-                    constexpr bool apply = INAFF && ta >= 0 && ta % G::EVERY == 0 && ta / G::EVERY < G::KD;
+                    // INAFF: which piece is in which stage in this tap.  tr = the tap of a piece's DMA whose read-back (stage 0) is
+                    // due now; ta1 / ta2 = those of the pieces one / two taps further on
+                    constexpr int tr = tap - 10, ta1 = tap - 11, ta2 = tap - 12;
+                    constexpr bool due1 = INAFF && ta1 >= 0 && ta1 % G::EVERY == 0 && ta1 / G::EVERY < G::KD;
+                    constexpr bool due2 = INAFF && NF == 1 && ta2 >= 0 && ta2 % G::EVERY == 0 && ta2 / G::EVERY < G::KD;
                     if constexpr (i == 1) {
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (INAFF) {  // (before this tap's LDS reads: the piece landed long ago, nothing is waited for)
@@ -1033,13 +1046,25 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                         if constexpr (G::dma_tap(tap)) dma(nxt, nfaces, nch_eff, std::integral_constant<int, tap / G::EVERY>{}, bufn);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (apply && i >= 2 && i <= 5) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (i == 2) aff_s1(aff_st);
-                        if constexpr (i == 3) aff_s2(aff_st);
-                        if constexpr (i == 4) aff_s3(aff_st);
-                        if constexpr (i == 5) aff_s4(aff_st, nfaces, aff_pb, std::integral_constant<int, (ta >= 0 ? ta : 0) / G::EVERY>{});
-                        __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (NF == 2) {
+                        if constexpr (due1 && i >= 2 && i <= 5) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (i == 2) aff_s1(aff_st);
+                            if constexpr (i == 3) aff_s2(aff_st);
+                            if constexpr (i == 4) aff_s3(aff_st);
+                            if constexpr (i == 5) aff_s4(aff_st, nfaces, aff_pb, std::integral_constant<int, (ta1 >= 0 ? ta1 : 0) / G::EVERY>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
+                        if constexpr ((due1 || due2) && (i == 2 || i == 3)) {
+                            static_assert(!(due1 && due2), "EVERY = 2: a tap holds either stages 1-2 of one piece or stages 3-4 of the one before");
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (due1 && i == 2) aff_s1(aff_st);
+                            if constexpr (due1 && i == 3) aff_s2(aff_st);
+                            if constexpr (due2 && i == 2) aff_s3(aff_st);
+                            if constexpr (due2 && i == 3) aff_s4(aff_st, nfaces, aff_pb, std::integral_constant<int, (ta2 >= 0 ? ta2 : 0) / G::EVERY>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 });
                 __builtin_amdgcn_sched_barrier(0);
@@ -1052,7 +1077,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
 #endif
                     const unsigned wl = wlane;
                     H16_WLOAD(wc[0], wb, 0);
-                    H16_WLOAD(wc[1], wb, 1024);
+                    if constexpr (NF == 2) H16_WLOAD(wc[1], wb, 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #ifdef MI355_H16_STAMPS
@@ -1061,7 +1086,7 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                 }
 #endif
             });
-            // this wave's DMAs have landed once at most the 40 weight loads issued after DMA 7 are outstanding; the barrier
+            // this wave's DMAs have landed once at most the weight loads issued after DMA 7 are outstanding; the barrier
             // publishes the brick (a ds_read is ordered behind an LDS-DMA only by the issuer's vmcnt + a barrier)
             H16_T(t_c2);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::after_last_dma) : "memory");
@@ -1078,21 +1103,51 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
         // The ring already holds the next tile's first nine taps, still in flight.  The compiler knows nothing of that: if it
         // moved one of those registers during the epilogue (a spill copy to an AGPR) it would copy what was there BEFORE the
         // load landed.  So the loads are retired here, with the ring as operands of the wait.
-        static_for<0, G::D>([&](auto t_c) { auto &w = wq[decltype(t_c)::value]; H16_WWAIT(w, 0); });
-        {
-            // ---- epilogue: LeakyReLU + fp16 in registers, transposed through this wave's LDS image, whole-line stores
-            typedef __attribute__((address_space(3))) char lds_char;
+        static_for<0, G::D>([&](auto t_c) { wwait(wq[decltype(t_c)::value], Zero{}); });
+        if constexpr (HEAD) {
+            // ---- fused 1x1x1 segmentation head (the network's last conv, Cout = 32): logits[c][voxel] = sum_cout Wh[c][cout] act[cout][voxel]
+            // on the matrix cores - the activation tile sits in the accumulators in the lane = voxel layout of an MFMA B operand
+            // (conv_epilogue_f16, HEAD); the feature map is never written.  Voxel l31 of fragment mf = (z = 2 wave + (mf >> 1),
+            // y = 4 (mf & 1) + (l31 >> 3), x = l31 & 7); class c = register c of the half-0 lanes.
+            const float slope = p.act == ACT_LRELU ? p.slope : 1.0f;
+            const unsigned Vo_h = (unsigned)(p.Do * p.Ho * p.Wo);   // (host: head_ncls * Vo * 4 < 2^32)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));   // (a tile-loop invariant of the plain lane id would be hoisted and spilled)
+            const unsigned lane_off_h = (unsigned)((((ln & 31) >> 3) * p.Wo + (ln & 7)) * 4);
+            float *hbase = p.head_out + (size_t)cur.n * p.head_ncls * Vo_h + ((size_t)(cur.oz0 + 2 * wave) * p.Ho + cur.oy0) * p.Wo + cur.ox0;  // wave-uniform
+            float hb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hb[c] = c < p.head_ncls ? p.head_b[c] : 0.f;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                f16x8 act[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float y = acc[mf][0][r];
+                    act[r >> 3][r & 7] = (half_t)fmaxf(y, y * slope);  // (the unfused path rounds the activation to fp16 before the head reads it)
+                }
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sl][1], act[sl], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sl][0], act[sl], d, 0, 0, 0);
+                }
+                if (ln < 32) {
+                    char *row = (char *)(hbase + ((size_t)(mf >> 1) * p.Ho + (mf & 1) * 4) * p.Wo) + lane_off_h;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < p.head_ncls) *(float *)(row + (size_t)c * Vo_h * 4) = d[c] + hb[c];
+                }
+            }
+        } else {
+            // ---- epilogue: LeakyReLU + fp16 in registers, whole-line stores straight from registers (v_permlane32_swap, round 3)
             const float slope = p.act == ACT_LRELU ? p.slope : 1.0f;  // max(x, 1*x) = x
-            unsigned img = (unsigned)(size_t)(lds_char *)(lds_raw + G::EPI_OFF) + wave * G::EPI_WAVE_BYTES;
-            unsigned wr = img + l31 * G::EPI_PITCH + half * 8;
-            asm volatile("" : "+v"(wr));
 #ifndef MI355_H16_SC1
 #define MI355_H16_SC1 1
 #endif
-#ifndef MI355_H16_EPI_SWAP
-#define MI355_H16_EPI_SWAP 1   // 0: round 2's transposition through a wave-private LDS image (A/B builds of tools/h16_probe.hip)
-#endif
-            // swap path: voxel l31 of fragment mf = (z = 2 wave + (mf >> 1), y = 4 (mf & 1) + (l31 >> 3), x = l31 & 7); lanes 32-63 store the
+            // voxel l31 of fragment mf = (z = 2 wave + (mf >> 1), y = 4 (mf & 1) + (l31 >> 3), x = l31 & 7); lanes 32-63 store the
             // next cout block (one block plane = Vo voxels x 16 B further)
             const size_t Vo_sw = (size_t)p.Do * p.Ho * p.Wo;
             // (32-bit, from a laundered lane id, HERE: as a loop invariant of the tile loop the 64-bit form was hoisted to the kernel
@@ -1142,36 +1197,32 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                                     }
                                 }
                             }
-                            if constexpr (MI355_H16_EPI_SWAP != 0) {
-                                // Whole-line stores WITHOUT the trip through LDS (round 3; cdna_hip_programming.md T21).  This lane holds
-                                // couts 0-3 (half 0) or 4-7 (half 1) of blocks gp and gp + 1 for voxel l31; v_permlane32_swap exchanges the
-                                // upper half-wave of its first operand with the lower half-wave of its second, after which lanes 0-31 hold
-                                // all 16 bytes of block gp and lanes 32-63 those of block gp + 1 for voxel l31.  The fragment's 32 voxels
-                                // are four x-rows of 8 (128 B each in a block's plane): one store = 8 whole lines, as before.
-                                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                                u32x2 a = __builtin_bit_cast(u32x2, val2[0]), b = __builtin_bit_cast(u32x2, val2[1]);
-                                // (inline asm: the pair-returning builtin is miscompiled by this hipcc, see common.h; s_nop 1 = the two wait
-                                //  states between a VALU write of an operand and the swap, and again before the store reads the result)
-                                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1"
-                                             : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
-                                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                                const u32x4 v = {a[0], a[1], b[0], b[1]};
-                                const char *row = (const char *)(obase_sw + (((size_t)(mf >> 1) * p.Ho + (mf & 1) * 4) * p.Wo + (size_t)(nf * 4 + gp) * Vo_sw) * 8);
-                                const unsigned lo = lane_off_sw;
-                                // (s_nop 1 behind the store: a VALU write of the data registers of a 16-byte store needs a wait state after
-                                //  its issue - hipcc pads its own stores, it does not look into inline asm, and the next pair's v_cvt_pk
-                                //  reuses these four registers at once: without the pad the statistics instantiations stored garbage)
-                                if constexpr (MI355_H16_SC1 != 0) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lo), "v"(v), "s"(row) : "memory");
-                                else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lo), "v"(v), "s"(row) : "memory");
-                            } else {
-                                *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + (nf * 32 + 8 * gp) * 2) = val2[0];
-                                *(__attribute__((address_space(3))) f16x4 *)(wr + mf * 32 * G::EPI_PITCH + (nf * 32 + 8 * gp + 8) * 2) = val2[1];
-                            }
+                            // Whole-line stores WITHOUT a trip through LDS (round 3; cdna_hip_programming.md T21).  This lane holds
+                            // couts 0-3 (half 0) or 4-7 (half 1) of blocks gp and gp + 1 for voxel l31; v_permlane32_swap exchanges the
+                            // upper half-wave of its first operand with the lower half-wave of its second, after which lanes 0-31 hold
+                            // all 16 bytes of block gp and lanes 32-63 those of block gp + 1 for voxel l31.  The fragment's 32 voxels
+                            // are four x-rows of 8 (128 B each in a block's plane): one store = 8 whole lines.
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            u32x2 a = __builtin_bit_cast(u32x2, val2[0]), b = __builtin_bit_cast(u32x2, val2[1]);
+                            // (inline asm: the pair-returning builtin is miscompiled by this hipcc, see common.h; s_nop 1 = the two wait
+                            //  states between a VALU write of an operand and the swap, and again before the store reads the result)
+                            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1"
+                                         : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+                            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                            const u32x4 v = {a[0], a[1], b[0], b[1]};
+                            const char *row = (const char *)(obase_sw + (((size_t)(mf >> 1) * p.Ho + (mf & 1) * 4) * p.Wo + (size_t)(nf * 4 + gp) * Vo_sw) * 8);
+                            const unsigned lo = lane_off_sw;
+                            // (s_nop 4 in front: `row` may have been reloaded from an SGPR spill lane by v_readlane_b32 right before
+                            //  the statement - five wait states hipcc does not pad inside inline asm, _isa_gate.py H1.  s_nop 1 behind
+                            //  the store: a VALU write of the data registers of a 16-byte store needs a wait state after its issue - hipcc
+                            //  pads its own stores, it does not look into inline asm, and the next pair's v_cvt_pk reuses these four
+                            //  registers at once: without the pad the statistics instantiations stored garbage)
+                            if constexpr (MI355_H16_SC1 != 0) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lo), "v"(v), "s"(row) : "memory");
+                            else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lo), "v"(v), "s"(row) : "memory");
                         }
                     if constexpr (STATS) {
                         // (round 3) transposing reduction, common.h: every lane ends with ONE total over the 32 voxel lanes of its
-                        // half-wave (x 4 fragments = this wave's 128 voxels) and adds it itself - no LDS, no barrier; round 2
-                        // reduced 32 values with butterflies, crossed the four waves through LDS and two __syncthreads().
+                        // half-wave (x 4 fragments = this wave's 128 voxels) and adds it itself - no LDS, no barrier.
                         // Quantised partials: exact additions in any order (common.h).
                         // (lane-dependent address parts from the laundered lane id `ln`: as tile-loop invariants of the plain lane id the
                         //  64-bit statistics address was hoisted to the kernel entry and spilled - 12 bytes of scratch, reloaded here by
@@ -1187,26 +1238,6 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
                 if (p.act == ACT_LRELU) transpose_out(std::true_type{}); else transpose_out(std::false_type{});
             } else {
                 transpose_out(std::true_type{});
-            }
-            // rows 8 j .. 8 j + 7 of the image are the x-row (z = 2 wave + (j >> 3), y = j & 7) of the tile: 8 voxels x 8 cout blocks.
-            // Blocked output: lane -> (block lane >> 3, voxel x = lane & 7): 8 lanes write the 128 contiguous bytes of a block's
-            // x-row, a store instruction eight whole lines
-            if constexpr (MI355_H16_EPI_SWAP == 0) {
-            unsigned rd = img + (lane & 7) * G::EPI_PITCH + (lane >> 3) * 16;
-            asm volatile("" : "+v"(rd));
-            const size_t Vo = (size_t)p.Do * p.Ho * p.Wo;
-            const unsigned lane_off = (unsigned)(((size_t)(lane >> 3) * Vo + (lane & 7)) * 16);  // (< 2^32: host check)
-            half_t *obase = p.out + (((size_t)cur.n * (p.Cout >> 3) + (co_blk >> 3)) * Vo + ((size_t)(cur.oz0 + 2 * wave) * p.Ho + cur.oy0) * p.Wo + cur.ox0) * 8;
-            static_for<0, 16>([&](auto j_c) {
-                constexpr int j = decltype(j_c)::value;
-                const f32x4 v = *(const __attribute__((address_space(3))) f32x4 *)(rd + j * 8 * G::EPI_PITCH);
-                const char *row = (const char *)(obase + ((size_t)(j >> 3) * p.Ho + (j & 7)) * p.Wo * 8);
-                const unsigned lo = lane_off;
-                // sc1: the output lines leave the XCD's L2 with the store - nothing on this XCD reads them again, and kept there
-                // they evict the brick lines whose next 32 bytes the next channel chunk is about to fetch
-                if constexpr (MI355_H16_SC1 != 0) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 0" ::"v"(lo), "v"(v), "s"(row) : "memory");
-                else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 0" ::"v"(lo), "v"(v), "s"(row) : "memory");
-            });
             }
         }
         cur = nxt_tile;
@@ -1224,7 +1255,22 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     }
 #endif
 #undef H16_WLOAD
-#undef H16_WWAIT
+}
+
+// 64 couts per workgroup, one wave per SIMD (128 accumulators per lane)
+template <bool STATS, bool INAFF = false>
+__global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
+    conv3_f16_dma_body<STATS, INAFF, 2, false>(p);
+}
+
+// Cout = 32 (round 5): the same body with ONE cout fragment per wave - 64 accumulators per lane, so TWO workgroups per CU (two
+// waves per SIMD): a wave's DMA issue stalls, its chunk barrier and its epilogue run beside the other workgroup's MFMAs.  With
+// half the MFMAs per brick a single workgroup per CU could not hide them (every DMA costs the wave ~130 cycles of issue; the
+// register-staged conv3_f16_mfma_pipe_kernel<4, 1, ...> these launches used before spent a quarter of its time staging: 870-980
+// TFLOP/s at 3.3-6.0 VALU instructions per MFMA).  HEAD: the network's last conv with the fused 1x1x1 head (model A).
+template <bool STATS, bool INAFF = false, bool HEAD = false>
+__global__ __launch_bounds__(256, 2) void conv3_f16_c32_kernel(ConvArgsH p) {
+    conv3_f16_dma_body<STATS, INAFF, 1, HEAD>(p);
 }
 
 // ------------------------------------------------------------------ host side
@@ -1395,40 +1441,64 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
             }
         }
     }
-    if (st == 1 && use_pipe_h() && w.nf == 2 && !c.head_out) {
-        // LDS-DMA kernel: 8 x 8 x 8 tiles x 64 couts, one workgroup per CU (MI355_F16_DMA=0: the register-staged kernel)
+    if (st == 1 && use_pipe_h() && (w.nf == 2 ? !c.head_out : (w.cout == 32 && (!c.head_out || (!c.stats && !c.in_scale))))) {
+        // LDS-DMA kernels: 8 x 8 x 8 tiles; conv3_f16_dma_kernel = 64 couts per workgroup, one workgroup per CU; conv3_f16_c32_kernel
+        // (round 5) = the Cout = 32 layers, two workgroups per CU (MI355_F16_DMA=0: the register-staged kernels)
         static int dmak = -1;
         if (dmak < 0) { const char *e = getenv("MI355_F16_DMA"); dmak = (e && e[0] == '0') ? 0 : 1; }
+        static int c32k = -1;
+        if (c32k < 0) { const char *e = getenv("MI355_F16_C32"); c32k = (e && e[0] == '0') ? 0 : 1; }
+        const bool c32 = w.nf == 1;
         ConvArgsH b = a;
         b.lx = b.ly = b.lz = 3;
         b.tiles_x = ceil_div(b.Wo, 8); b.tiles_y = ceil_div(b.Ho, 8); b.tiles_z = ceil_div(b.Do, 8);
         b.IX = b.IY = b.IZ = 10;
         b.div_tiles_per_n = make_fastdiv(b.tiles_x * b.tiles_y * b.tiles_z);
         const long tiles = (long)b.tiles_x * b.tiles_y * b.tiles_z * c.N;
-        typedef DmaGeomH<2> GA;
+        typedef DmaGeomH<2, 2> GA;
+        typedef DmaGeomH<2, 1> GA1;
+        const int wg_per_cu = c32 ? GA1::WG_PER_CU : GA::WG_PER_CU;
         const size_t tab_bytes = c.in_scale ? (size_t)c.N * c.C0 * 4 : 0;  // fused input norm: fp16 scale + shift tables in LDS
-        if (dmak && tiles * gy >= 256 && tiles < (1l << 30) && b.Do % 8 == 0 && b.Ho % 8 == 0 && b.Wo % 8 == 0 &&
+        const size_t tab_max = c32 ? (size_t)GA1::TAB_MAX_BYTES : (size_t)GA::TAB_MAX_BYTES;
+        if (dmak && (!c32 || c32k) && tiles * gy >= 256 * wg_per_cu && tiles < (1l << 30) && b.Do % 8 == 0 && b.Ho % 8 == 0 && b.Wo % 8 == 0 &&
             (long)10 * c.Hi * c.Wi < (1l << 24) && ((long)10 * c.Hi * c.Wi + 8l * c.Di * c.Hi * c.Wi) * 16 < (1l << 32) &&
-            (!c.in_scale || (c.C1 == 0 && tab_bytes <= (size_t)GA::TAB_MAX_BYTES))) {
+            (!c.in_scale || (c.C1 == 0 && tab_bytes <= tab_max)) &&
+            (!c.head_out || (long)c.head_ncls * c.Di * c.Hi * c.Wi * 4 < (1l << 32))) {
             void *zeros = nullptr;  // the zero page out-of-volume DMA pieces read
             MI355_TRY(device_scratch(SCR_ZEROS, s, 256, &zeros, true));
             b.zeros = zeros;
             b.total_tiles = (int)tiles;
             b.order = make_tile_order(b.tiles_x, b.tiles_y, b.tiles_z);
-            int gx = 256 / gy;
+            int gx = 256 * wg_per_cu / gy;
             gx = gx < 8 ? 8 : (gx / 8) * 8;
             const int need = (int)((tiles + 7) / 8) * 8;
             if (gx > need) gx = need;
+            const size_t lds_plain = GA::LDS_BYTES, lds_aff = (size_t)GA::TAB_OFF + tab_bytes;   // (the same layout for both fragment counts)
+            static_assert(GA::LDS_BYTES == GA1::LDS_BYTES && GA::TAB_OFF == GA1::TAB_OFF, "one LDS layout");
+            if (c32) {
+                static size_t attr_c32[5] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+                if (c.head_out) {
+                    if (kernel_name) *kernel_name = "conv3_f16_c32_kernel<false, false, true>";
+                    return launch_h(conv3_f16_c32_kernel<false, false, true>, b, dim3(gx, gy), lds_plain, s, &attr_c32[4]);
+                }
+                if (c.in_scale) {
+                    if (kernel_name) *kernel_name = c.stats ? "conv3_f16_c32_kernel<true, true, false>" : "conv3_f16_c32_kernel<false, true, false>";
+                    if (c.stats) return launch_h(conv3_f16_c32_kernel<true, true>, b, dim3(gx, gy), lds_aff, s, &attr_c32[2]);
+                    return launch_h(conv3_f16_c32_kernel<false, true>, b, dim3(gx, gy), lds_aff, s, &attr_c32[3]);
+                }
+                if (kernel_name) *kernel_name = c.stats ? "conv3_f16_c32_kernel<true, false, false>" : "conv3_f16_c32_kernel<false, false, false>";
+                if (c.stats) return launch_h(conv3_f16_c32_kernel<true>, b, dim3(gx, gy), lds_plain, s, &attr_c32[0]);
+                return launch_h(conv3_f16_c32_kernel<false>, b, dim3(gx, gy), lds_plain, s, &attr_c32[1]);
+            }
             static size_t attr_dma[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
             if (c.in_scale) {
-                const size_t lds_aff = (size_t)GA::TAB_OFF + tab_bytes;
                 if (kernel_name) *kernel_name = c.stats ? "conv3_f16_dma_kernel<true, true>" : "conv3_f16_dma_kernel<false, true>";
                 if (c.stats) return launch_h(conv3_f16_dma_kernel<true, true>, b, dim3(gx, gy), lds_aff, s, &attr_dma[2]);
                 return launch_h(conv3_f16_dma_kernel<false, true>, b, dim3(gx, gy), lds_aff, s, &attr_dma[3]);
             }
             if (kernel_name) *kernel_name = c.stats ? "conv3_f16_dma_kernel<true, false>" : "conv3_f16_dma_kernel<false, false>";
-            if (c.stats) return launch_h(conv3_f16_dma_kernel<true>, b, dim3(gx, gy), DmaGeomH<3>::LDS_BYTES, s, &attr_dma[0]);
-            return launch_h(conv3_f16_dma_kernel<false>, b, dim3(gx, gy), DmaGeomH<3>::LDS_BYTES, s, &attr_dma[1]);
+            if (c.stats) return launch_h(conv3_f16_dma_kernel<true>, b, dim3(gx, gy), lds_plain, s, &attr_dma[0]);
+            return launch_h(conv3_f16_dma_kernel<false>, b, dim3(gx, gy), lds_plain, s, &attr_dma[1]);
         }
     }
     if (st == 1 && use_pipe_h()) {

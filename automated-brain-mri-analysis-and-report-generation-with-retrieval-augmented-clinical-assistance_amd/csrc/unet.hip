@@ -659,6 +659,9 @@ extern "C" int mi355_unet_create(const mi355_unet_desc *d, mi355_unet_t *out) {
     MI355_REQUIRE(d->num_pool >= 1 && d->num_pool <= 7, "num_pool %d out of range", d->num_pool);
     MI355_REQUIRE(d->in_channels >= 1 && d->in_channels <= 8, "in_channels %d unsupported (1..8)", d->in_channels);
     MI355_REQUIRE(d->norm >= MI355_NORM_NONE && d->norm <= MI355_NORM_GROUP, "norm kind %d", d->norm);
+    // every kernel computes LeakyReLU as max(x, slope * x), which is LeakyReLU for 0 <= slope <= 1 only; the
+    // reference's is 0.01 (generic_UNet.py:39)
+    MI355_REQUIRE(d->lrelu_slope >= 0.f && d->lrelu_slope <= 1.f, "lrelu_slope %g outside [0, 1]: the kernels evaluate LeakyReLU as max(x, slope x)", (double)d->lrelu_slope);
     mi355_unet *net = new mi355_unet();
     net->in_channels = d->in_channels; net->cin_pad = d->dtype == MI355_F16 ? 16 : 8; net->num_classes = d->num_classes;
     const bool use_stem = d->in_channels <= 4 && d->n_convs > 0 && d->convs[0].cout % 32 == 0 && d->convs[0].stride == 1 &&
@@ -899,6 +902,7 @@ static int conv3d_ndhwc_f32_impl(const float *x_dev, int n, int d, int h, int w,
                                  const float *bias_host, int cout, int stride, int act, float slope, int impl, float *y_dev,
                                  double *sums, void *stream) {
     MI355_TRY(require_device());
+    MI355_REQUIRE(act != ACT_LRELU || (slope >= 0.f && slope <= 1.f), "LeakyReLU slope %g outside [0, 1]", (double)slope);
     if (sums) MI355_HIP(hipMemsetAsync(sums, 0, (size_t)n * cout * 2 * sizeof(double), (hipStream_t)stream));
     if (cin == 4 && stride == 1 && impl == 0 && cout % 32 == 0) {  // the network's first-layer kernel
         StemWeights sw;
@@ -959,6 +963,7 @@ static int conv3d_ndhwc_f16_impl(const void *x_dev, int n, int d, int h, int w, 
                                  double *sums, void *stream) {
     MI355_TRY(require_device());
     MI355_REQUIRE(stride == 1 || stride == 2, "conv stride %d unsupported", stride);
+    MI355_REQUIRE(act != ACT_LRELU || (slope >= 0.f && slope <= 1.f), "LeakyReLU slope %g outside [0, 1]", (double)slope);
     hipStream_t s = (hipStream_t)stream;
     if (sums) MI355_HIP(hipMemsetAsync(sums, 0, (size_t)n * cout * 2 * sizeof(double), s));
     const int64_t Vi = (int64_t)d * h * w;

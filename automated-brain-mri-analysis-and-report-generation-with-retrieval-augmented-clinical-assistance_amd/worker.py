@@ -69,6 +69,24 @@ class _SocketWriter(io.TextIOBase):
         pass
 
 
+def _is_device_failure(e, mi355_error_type) -> bool:
+    """A failed library call, or an error raised by torch's device runtime.  Classified by TYPE (a substring test on the
+    message took '/data/ship01/case.nii.gz not found' for a HIP error and ended the serve loop): Mi355Error; torch's
+    AcceleratorError / OutOfMemoryError / DeferredCudaCallError; a bare RuntimeError only when torch itself raised it from its
+    CUDA/HIP layer, which it marks with the prefix 'CUDA error' / 'HIP error'."""
+    if isinstance(e, mi355_error_type):
+        return True
+    try:
+        import torch
+        kinds = tuple(k for k in (getattr(torch, "AcceleratorError", None), getattr(torch.cuda, "OutOfMemoryError", None),
+                                  getattr(torch.cuda, "DeferredCudaCallError", None)) if isinstance(k, type))
+        if kinds and isinstance(e, kinds):
+            return True
+    except Exception:
+        pass
+    return type(e) is RuntimeError and str(e).startswith(("CUDA error", "HIP error"))
+
+
 def _handle(conn, cache, state):
     from . import driver
     fh = conn.makefile("rw", encoding="utf-8", newline="\n")
@@ -97,7 +115,7 @@ def _handle(conn, cache, state):
                 print(traceback.format_exc())
                 rc = 1
                 from ._lib import Mi355Error
-                if isinstance(e, Mi355Error) or "HIP" in type(e).__name__ or "hip" in str(e).lower():
+                if _is_device_failure(e, Mi355Error):
                     # a failed library call or a HIP error may be sticky (a faulted context fails every later launch): answer
                     # this request, then leave the serve loop so that a supervisor starts a fresh process and later clients
                     # fall back to in-process runs instead of collecting rc = 1 forever.  Never re-exec a GPU process.
@@ -118,6 +136,13 @@ def serve(socket_path: str, preload=None, ready_fd=None):
     sock_dir = os.path.dirname(socket_path)
     if sock_dir and not os.path.isdir(sock_dir):
         os.makedirs(sock_dir, mode=0o700, exist_ok=True)
+    if sock_dir:
+        # the directory must be ours and closed to others, whether we made it or found it: another local user who pre-creates
+        # /tmp/mi355_nnunet_<uid> could otherwise unlink or replace the socket
+        st = os.lstat(sock_dir)
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise SystemExit(f"{sock_dir} is not a directory owned by uid {os.getuid()} with mode 0700: refusing to bind a worker socket in it")
     if os.path.exists(socket_path):
         # a stale socket of a dead worker is replaced; a live one answers the ping and we refuse to start a second worker
         with contextlib.suppress(OSError), socket.socket(socket.AF_UNIX, socket.SOCK_STREAM) as probe:

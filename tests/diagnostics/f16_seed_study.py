@@ -43,10 +43,13 @@ def main():
     ap.add_argument("--models", default="A,B")
     ap.add_argument("--sets", type=int, default=5)
     ap.add_argument("--volumes", type=int, default=2)
+    ap.add_argument("--noise", type=int, default=0, help="also that many 128^3 Gaussian-noise tiles (RandomState 2, 3, ...: the tile128 fixture of "
+                                                        "tests/test_gpu_network.py is seed 2), listed as volumes 2, 3, ...")
     args = ap.parse_args()
     from oracle import tiler_ref
     dev = torch.device("cuda", 0)
-    tiles = [first_tile(1000 + v, dev) for v in range(args.volumes)]
+    tiles = [(1000 + v, first_tile(1000 + v, dev)) for v in range(args.volumes)]
+    tiles += [(2 + k, torch.from_numpy(np.random.RandomState(2 + k).standard_normal((4, 128, 128, 128)).astype(np.float32)).to(dev)) for k in range(args.noise)]
 
     def dice(a, b):
         la, lb = tiler_ref.regions_to_labels(a), tiler_ref.regions_to_labels(b)
@@ -62,7 +65,7 @@ def main():
             res = {}
             for dtype in ("f32", "f16"):
                 nets = [amd.UNet(sd, norm=m["norm"], num_groups=m["num_groups"], dtype=dtype) for sd, m in sds]
-                for v, tile in enumerate(tiles):
+                for v, (_, tile) in enumerate(tiles):
                     run = lambda ns, tta: predictor.predict_folds(ns, tile, PATCH, 0.5, tta, (0, 1, 2), True, "sigmoid").cpu().numpy()  # noqa: E731
                     res[dtype, v, "single"] = run(nets[:1], False)
                     res[dtype, v, "single_tta"] = run(nets[:1], True)
@@ -74,12 +77,13 @@ def main():
                 for key, what in SETTINGS:
                     d, nd = dice(res["f16", v, key], res["f32", v, key])
                     perr = float(np.abs(res["f16", v, key] - res["f32", v, key]).max())
-                    summary.setdefault((name, key), []).append(d)
-                    print(f"SEEDSTUDY {args.tag} {name} set {s} volume {1000 + v} {what}: Dice {d:.6f} ({nd} labels differ), prob err {perr:.4f}", flush=True)
-    for (name, key), ds in summary.items():
+                    kind = "brain" if tiles[v][0] >= 1000 else "noise"
+                    summary.setdefault((name, kind, key), []).append(d)
+                    print(f"SEEDSTUDY {args.tag} {name} set {s} {kind} volume {tiles[v][0]} {what}: Dice {d:.6f} ({nd} labels differ), prob err {perr:.4f}", flush=True)
+    for (name, kind, key), ds in summary.items():
         what = dict(SETTINGS)[key]
         ds = np.array(ds)
-        print(f"SEEDSTUDY {args.tag} SUMMARY {name} {what}: n {len(ds)}  min {ds.min():.6f}  median {np.median(ds):.6f}  max {ds.max():.6f}  "
+        print(f"SEEDSTUDY {args.tag} SUMMARY {name} {kind} tiles {what}: n {len(ds)}  min {ds.min():.6f}  median {np.median(ds):.6f}  max {ds.max():.6f}  "
               f"below 0.999: {int((ds < 0.999).sum())}  below 0.9993: {int((ds < 0.9993).sum())}", flush=True)
 
 

@@ -235,3 +235,22 @@ def test_worker_protocol_without_a_gpu(amd, tmp_path, monkeypatch):
     assert not t.is_alive() and not os.path.exists(sock)
     monkeypatch.setenv("MI355_NO_WORKER", "1")
     assert worker.request(argv, "/sd", sock) is None
+
+
+def test_worker_failure_classification_and_socket_directory(amd, tmp_path):
+    """an ordinary error whose text happens to contain 'hip' must not end the serve loop; a socket directory that is not
+    ours alone is refused."""
+    from brats_amd import worker
+    from brats_amd._lib import Mi355Error
+    assert worker._is_device_failure(Mi355Error("mi355_sw_predict failed"), Mi355Error)
+    assert worker._is_device_failure(RuntimeError("HIP error: invalid device function"), Mi355Error)
+    assert worker._is_device_failure(RuntimeError("CUDA error: an illegal memory access was encountered"), Mi355Error)
+    assert not worker._is_device_failure(FileNotFoundError("/data/ship01/case_t1.nii.gz not found"), Mi355Error)
+    assert not worker._is_device_failure(ValueError("data must be [C=4, Z, Y, X] (membership of this hip class)"), Mi355Error)
+    assert not worker._is_device_failure(RuntimeError("plans: the checkpoint was written for another patch size (hipify?)"), Mi355Error)
+    open_dir = tmp_path / "shared"
+    open_dir.mkdir(mode=0o755)
+    os.chmod(open_dir, 0o755)
+    with pytest.raises(SystemExit) as ei:
+        worker.serve(str(open_dir / "w.sock"))
+    assert "0700" in str(ei.value)

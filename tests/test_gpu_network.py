@@ -19,13 +19,23 @@ LOGIT_REL_TOL = 6e-5   # x logit spread.  Measured on MI355X (round 2): 0.7-4.7e
                        # regression of the Winograd numerics by 1.6x already fails
 
 
-def _check_logits(got, ref, what="", rel_tol=None):
+ABS_LOGIT_TOL = 1e-3   # north_star, read literally: "softmax logits within 1e-3 fp32"
+
+
+def _check_logits(got, ref, what="", rel_tol=None, abs_tol=ABS_LOGIT_TOL):
+    """Which reading of the north_star's "logits within 1e-3" the suite enforces: ALL of them.  SURVEY.md 8d
+    reads it as class PROBABILITIES within 1e-3 (what decides a label; gated here); the logits are gated relative to their spread
+    (a regression detector: 6e-5 x spread is 1.6 x the worst fp32 case measured) AND, read literally, at 1e-3 absolute - for the
+    synthetic heads with a logit spread above 16.7 the absolute bound is the tighter of the two (model A at 128^3: spread 24,
+    measured 9.2e-4)."""
     rel_tol = LOGIT_REL_TOL if rel_tol is None else rel_tol
     spread = float(ref.std())
     err = float(np.abs(got - ref).max())
     perr = float(np.abs(1 / (1 + np.exp(-got.astype(np.float64))) - 1 / (1 + np.exp(-ref.astype(np.float64)))).max())
     print(f"PARITY {what}: logit max abs err {err:.3e} = {err / max(spread, 1.0):.2e} x spread ({spread:.2f}), prob err {perr:.2e}")
     assert err <= rel_tol * max(spread, 1.0), f"logit max abs err {err} (spread {spread})"
+    if abs_tol is not None:
+        assert err <= abs_tol, f"logit max abs err {err} > {abs_tol} (spread {spread})"
     assert perr <= PROB_TOL, f"sigmoid prob err {perr}"
 
 
@@ -232,9 +242,20 @@ def test_forward_f16_64_matches_oracle(amd, gpu, name):
     net = amd.UNet(sd, norm=meta["norm"], num_groups=meta["num_groups"], dtype="f16")
     x = np.random.RandomState(1).standard_normal((1, 4, 64, 64, 64)).astype(np.float32)
     ref = unet_ref.unet_forward(sd, x, unet_ref.default_cfg(norm=meta["norm"], num_groups=meta["num_groups"])).numpy()
+    net.profile(True)
     got = net(torch.from_numpy(x).to(gpu)).cpu().numpy()
+    kernels = {e["name"] for e in net.read_profile()}
+    net.profile(False)
     rel = _check_logits_f16(got, ref, prob_tol=0.08 if name == "A_in" else 0.05)
     print(f"fp16 {name}: max logit err / spread = {rel:.2e}")
+    # round 5: the Cout = 32 layers of the full-resolution level (512 tiles of 8^3 at 64^3) run on the LDS-DMA kernel with two
+    # workgroups per CU - model A incl. its fused-head instantiation, the Instance/GroupNorm models incl. the one that normalises
+    # its producer's output in LDS and carries the statistics epilogue
+    import os
+    if not any(k in os.environ for k in ("MI355_CONV_IMPL", "MI355_F16_DMA", "MI355_F16_C32", "MI355_FUSE_NORM", "MI355_FUSE_HEAD")):
+        want = {"A": {"conv3_f16_c32_kernel<false, false, false>", "conv3_f16_c32_kernel<false, false, true>"},
+                "A_in": {"conv3_f16_c32_kernel<true, true, false>"}, "B": {"conv3_f16_c32_kernel<true, true, false>"}}[name]
+        assert want <= kernels, sorted(kernels)
     net.close()
 
 
@@ -280,7 +301,8 @@ np.savez(sys.argv[1], y=y, names=np.array(names))
             outs[flag] = np.load(path)
     fused, plain = outs["1"], outs["0"]
     def inaff(n):  # conv3_f16_mfma_pipe_kernel<MF, NF, HEAD, INAFF, STRIDE, WHOLE> / conv3_f16_dma_kernel<STATS, INAFF>
-        return ("pipe_kernel<" in n and n.split("<")[1].split(",")[3].strip() == "true") or ("dma_kernel<" in n and n.endswith(", true>"))
+        return (("pipe_kernel<" in n and n.split("<")[1].split(",")[3].strip() == "true") or ("dma_kernel<" in n and n.endswith(", true>")) or
+                ("c32_kernel<" in n and n.split("<")[1].split(",")[1].strip() == "true"))   # conv3_f16_c32_kernel<STATS, INAFF, HEAD>
     assert any(inaff(n) for n in fused["names"]), list(fused["names"])         # the INAFF kernels ran ...
     assert any("dma_kernel<" in n and inaff(n) for n in fused["names"]), list(fused["names"])   # ... the in-LDS variant among them
     assert not any(inaff(n) for n in plain["names"])

@@ -219,6 +219,9 @@ F16_CONV_CASES = [
     (2, 64, 64, 64, 32, 128, 2, 1),  # round 3: stride 2, Cout % 128 == 0, whole 4 x 4 x 8 output tiles -> conv3_f16_s2dma_kernel, 2 chunks
     (2, 32, 32, 64, 64, 256, 2, 0),  # the same kernel: two cout blocks of 128, 4 chunks, no activation
     (6, 24, 40, 48, 16, 128, 2, 1),  # the same kernel: one chunk, 3 x 5 x 3 tiles (linear tile order), 270 tiles (uneven XCD split), batch 6
+    (8, 32, 32, 32, 32, 32, 1, 1),   # round 5: Cout = 32 on whole 8^3 tiles, 512 tiles = two workgroups per CU: conv3_f16_c32_kernel, 2 chunks
+    (8, 32, 32, 32, 64, 32, 1, 0),   # the same kernel: 4 chunks, no activation
+    (4, 24, 40, 72, 16, 32, 1, 1),   # the same kernel: one chunk, odd tile counts (3 x 5 x 9, linear tile order), 540 tiles (uneven XCD split)
 ]
 
 #: which kernel a case is written for (asserted through mi355_last_conv_kernel; ADVICE r2: a case that claims a kernel must run on it)
@@ -232,6 +235,10 @@ F16_EXPECT_KERNEL = {
     (6, 24, 40, 48, 16, 128, 2, 1): "conv3_f16_s2dma_kernel<false, 128>",
     (2, 64, 64, 128, 32, 64, 2, 1): "conv3_f16_s2dma_kernel<false, 64>",
     (8, 8, 8, 8, 320, 320, 1, 1): "conv3_f16_mfma_kernel<1, 2, 2> split-K",
+    (8, 32, 32, 32, 32, 32, 1, 1): "conv3_f16_c32_kernel<false, false, false>",
+    (8, 32, 32, 32, 64, 32, 1, 0): "conv3_f16_c32_kernel<false, false, false>",
+    (4, 24, 40, 72, 16, 32, 1, 1): "conv3_f16_c32_kernel<false, false, false>",
+    (8, 16, 16, 32, 32, 32, 1, 1): "conv3_f16_mfma_pipe_kernel<4, 1, false, false, 1, true>",   # (128 tiles: too few for the Cout = 32 LDS-DMA kernel)
 }
 
 
@@ -252,7 +259,7 @@ def test_conv3d_f16_matches_torch(amd, gpu, case):
     err = np.abs(y - ref).max()
     assert err <= 2e-3 * max(1.0, np.abs(ref).max()), f"max abs err {err} ({ran})"
     import os
-    if case in F16_EXPECT_KERNEL and not any(k in os.environ for k in ("MI355_CONV_IMPL", "MI355_F16_DMA", "MI355_F16_S2", "MI355_S2_DMA", "MI355_SPLITK")):
+    if case in F16_EXPECT_KERNEL and not any(k in os.environ for k in ("MI355_CONV_IMPL", "MI355_F16_DMA", "MI355_F16_C32", "MI355_F16_S2", "MI355_S2_DMA", "MI355_SPLITK")):
         assert ran == F16_EXPECT_KERNEL[case], ran
 
 
@@ -264,6 +271,8 @@ SUMS_CASES = [
     (2, 64, 64, 64, 32, 128, 2, 0, "f16"),   # stride-2 LDS-DMA kernel
     (2, 64, 64, 64, 32, 64, 2, 0, "f16"),    # the same kernel with 64 couts per workgroup (waves split 2 x 2: couts x z planes)
     (8, 16, 16, 32, 32, 32, 1, 0, "f16"),    # register-staged kernel, 512-voxel tiles, Cout = 32
+    (8, 32, 32, 32, 32, 32, 1, 0, "f16"),    # round 5: the Cout = 32 LDS-DMA kernel, statistics, no activation
+    (4, 24, 40, 72, 16, 32, 1, 1, "f16"),    # the same kernel with an activation in front of the statistics, odd tile counts
     (2, 8, 12, 40, 16, 64, 1, 1, "f16"),     # the same family, ragged tiles: voxels beyond the edge must not count
     (3, 9, 7, 131, 48, 96, 2, 0, "f16"),     # stride 2, odd dims, ragged
     (2, 8, 12, 40, 4, 32, 1, 0, "f16"),      # first layer (Cin = 4), ragged in y
@@ -279,6 +288,8 @@ SUMS_CASES = [
 SUMS_EXPECT_KERNEL = {
     (8, 32, 32, 32, 64, 64, 1, 0, "f16"): "conv3_f16_dma_kernel<true, false>",
     (4, 24, 40, 72, 16, 64, 1, 1, "f16"): "conv3_f16_dma_kernel<true, false>",
+    (8, 32, 32, 32, 32, 32, 1, 0, "f16"): "conv3_f16_c32_kernel<true, false, false>",
+    (4, 24, 40, 72, 16, 32, 1, 1, "f16"): "conv3_f16_c32_kernel<true, false, false>",
     (2, 64, 64, 64, 32, 128, 2, 0, "f16"): "conv3_f16_s2dma_kernel<true, 128>",
     (2, 64, 64, 64, 32, 64, 2, 0, "f16"): "conv3_f16_s2dma_kernel<true, 64>",
     (8, 32, 32, 32, 32, 32, 1, 0, "f32"): "conv3_f32_wino3_kernel<2, false>",
@@ -315,7 +326,7 @@ def test_conv3d_norm_sums_match_reference(amd, gpu, case):
     msq_err = np.abs(sums[..., 1] / V - msq_ref) / msq_ref
     assert mean_err.max() <= 1e-4 and msq_err.max() <= 1e-4, f"mean err {mean_err.max():.2e} rms, mean-square err {msq_err.max():.2e} ({ran})"
     import os
-    if case in SUMS_EXPECT_KERNEL and not any(k in os.environ for k in ("MI355_CONV_IMPL", "MI355_F16_DMA", "MI355_F16_S2", "MI355_S2_DMA", "MI355_WINOGRAD", "MI355_WINO3")):
+    if case in SUMS_EXPECT_KERNEL and not any(k in os.environ for k in ("MI355_CONV_IMPL", "MI355_F16_DMA", "MI355_F16_C32", "MI355_F16_S2", "MI355_S2_DMA", "MI355_WINOGRAD", "MI355_WINO3")):
         assert ran == SUMS_EXPECT_KERNEL[case], ran
 
 
