@@ -1020,7 +1020,11 @@ __device__ __forceinline__ void conv3_f16_dma_body(const ConvArgsH &p) {
                 wwait(wc, std::integral_constant<int, G::pending(tap)>{});
                 // the first MFMAs go out before the tap's memory instructions: the compiler waits for ALL outstanding LDS
                 // reads before the first MFMA of a tap (lgkmcnt(0): it will not count past an LDS-DMA), so the reads of tap
-                // t+1 are issued behind two MFMAs of tap t and are a tap old when that wait comes
+                // t+1 are issued behind two MFMAs of tap t (NF = 2: six more to land behind) or behind one (NF = 1: three more)
+#ifndef MI355_C32_MEM_AT
+#define MI355_C32_MEM_AT 0
+#endif
+                constexpr int MEM_AT = NF == 2 ? 1 : MI355_C32_MEM_AT;
                 static_for<0, MF * NF>([&](auto i_c) {
                     constexpr int i = decltype(i_c)::value;
                     constexpr int mf = i / NF, nf = i % NF;
@@ -1030,7 +1034,7 @@ __device__ __forceinline__ void conv3_f16_dma_body(const ConvArgsH &p) {
                     constexpr int tr = tap - 10, ta1 = tap - 11, ta2 = tap - 12;
                     constexpr bool due1 = INAFF && ta1 >= 0 && ta1 % G::EVERY == 0 && ta1 / G::EVERY < G::KD;
                     constexpr bool due2 = INAFF && NF == 1 && ta2 >= 0 && ta2 % G::EVERY == 0 && ta2 / G::EVERY < G::KD;
-                    if constexpr (i == 1) {
+                    if constexpr (i == MEM_AT) {
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (INAFF) {  // (before this tap's LDS reads: the piece landed long ago, nothing is waited for)
                             if constexpr (tr >= 0 && tr % G::EVERY == 0 && tr / G::EVERY < G::KD)

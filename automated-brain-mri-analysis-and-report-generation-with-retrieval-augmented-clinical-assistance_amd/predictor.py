@@ -112,8 +112,11 @@ def predict_folds(nets: Sequence[UNet], data, patch_size=(128, 128, 128), step_s
         from . import ops
         n_items = len(nets) * int(np.prod([len(ops.compute_steps(int(p), max(int(p), int(d)), float(step_size)))
                                            for p, d in zip(patch_size, (z, y, x))]))
-        # (every lane needs at least one full forward batch for the split to pay: 2 items per lane)
-        if n_items >= 2 * lanes:
+        # (the split pays when every lane still runs full forward batches - 32 samples = (tile, mirror) pairs per lane; measured:
+        #  config 3 fp16, 8 tiles x 8 mirrors per member: 273 -> 266 ms with two lanes, 272 with three; config 2, 8 tiles without
+        #  mirrors: 28.3 ms either way, so it stays on one lane and bit-identical with mi355_sw_predict)
+        n_mirrors = 2 ** len(set(mirror_axes)) if do_mirroring else 1
+        if n_items * n_mirrors >= 32 * lanes:
             return _predict_folds_lanes(nets, data, lanes, patch_size, step_size, do_mirroring, mirror_axes, use_gaussian, nonlin, batch_tiles)
     k = nets[0].topology.num_classes
     probs = torch.empty((k, z, y, x), dtype=torch.float32, device=data.device)

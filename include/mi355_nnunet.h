@@ -29,8 +29,11 @@
  * hipStream_t passed as void* (NULL = default stream).  ONE PROCESS PER GPU: the library binds
  * to the HIP device that is current at its first compute call (weights, arena and scratch
  * buffers live there) and every later call fails with MI355_ERR_INVALID while another device
- * is current.  The arena and scratch are shared by all handles: issue work on one stream at a
- * time; a handle must not be used from two threads at once.  There is NO CPU fallback: on a
+ * is current.  The activation arena and every scratch buffer exist once per STREAM ("lane", round 5): work
+ * issued on one stream is ordered by that stream and shares its arena across handles; up to four streams may
+ * carry work at the same time (a fifth takes over the least recently used lane after a device synchronise).
+ * A handle may be used on two streams at once (its weights are read-only); not from two threads while its
+ * profiling log is enabled.  There is NO CPU fallback: on a
  * machine without a gfx950 device every compute entry point fails with MI355_ERR_NO_DEVICE.
  */
 #ifndef MI355_NNUNET_H

@@ -238,7 +238,7 @@ F16_EXPECT_KERNEL = {
     (8, 32, 32, 32, 32, 32, 1, 1): "conv3_f16_c32_kernel<false, false, false>",
     (8, 32, 32, 32, 64, 32, 1, 0): "conv3_f16_c32_kernel<false, false, false>",
     (4, 24, 40, 72, 16, 32, 1, 1): "conv3_f16_c32_kernel<false, false, false>",
-    (8, 16, 16, 32, 32, 32, 1, 1): "conv3_f16_mfma_pipe_kernel<4, 1, false, false, 1, true>",   # (128 tiles: too few for the Cout = 32 LDS-DMA kernel)
+    (8, 16, 16, 32, 32, 32, 1, 1): "conv3_f16_mfma_pipe_kernel<2, 1, false, false, 1, true>",   # (128 tiles: too few for the Cout = 32 LDS-DMA kernel)
 }
 
 

@@ -74,7 +74,14 @@ static int run(int N, int D, int cin, int cout, int reps, bool inaff = false, bo
     return 0;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    if (argc > 1 && argv[1][0] == 'c') {  // the Cout = 32 layers of the full-resolution level (conv3_f16_c32_kernel, round 5)
+        if (run(8, 128, 32, 32, 3)) return 1;
+        if (run(8, 128, 64, 32, 3)) return 1;
+        if (run(8, 128, 64, 32, 3, true, true)) return 1;
+        return 0;
+    }
     // the same shape plain, with IN/GN statistics, and with the producer's norm applied in LDS (what INAFF costs, and where)
     if (run(8, 64, 64, 64, 5)) return 1;
     if (run(8, 64, 64, 64, 5, false, true)) return 1;
