@@ -6,12 +6,11 @@
 // of a stride-1 brick - and round 2's kernel for these layers (conv3_f16_mfma_pipe_kernel<1,2,..,2>) spent its time there:
 // 0.15 of the fp16 MFMA peak, 5.9 VALU instructions per MFMA, and with ONE voxel fragment per wave (32 voxels x 64 couts)
 // every pair of MFMAs pulled 2 KB of weights through the L1.  Here:
-//   * workgroup tile = 128 outputs (4 x 4 x 8) x 128 couts; the waves SHARE the voxel fragments (LDS) and split the couts and the
-//     output z planes: round 3 had four waves of 128 voxels x 32 couts each (MF = 4: a tap is 4 MFMAs for ONE 1-KiB weight
-//     fragment from the L1 and four 1-KiB voxel fragments from the LDS); round 5 has EIGHT waves of 64 voxels x 32 couts (MF = 2),
-//     two per SIMD, so that one wave's DMA issue, chunk barrier and epilogue run beside its partner's MFMAs (see the kernel);
+//   * workgroup tile = 128 outputs (4 x 4 x 8) x 128 couts; the four waves SHARE the voxel fragments (LDS) and split the
+//     couts: a wave owns 128 voxels x 32 couts (MF = 4, NF = 1, 64 accumulator registers), so a tap is 4 MFMAs for ONE
+//     1-KiB weight fragment from the L1 (0.25 KB per MFMA instead of 1) and four 1-KiB voxel fragments from the LDS;
 //   * the brick (9 x 9 x 17 voxels x 16 channels) is double-buffered and filled by LDS-DMA (global_load_lds_dwordx4: no
-//     staging registers, no ds_write, ~7 VALU per 1-KiB piece), 7 pieces per wave and chunk, one every third tap;
+//     staging registers, no ds_write, ~7 VALU per 1-KiB piece), 13 pieces per wave and chunk, one every second tap;
 //   * LDS image of the brick: planar [8-channel half][z][y][x parity][x / 2] with 20-slot rows (9 even + 8 odd x, 3 pad
 //     slots).  The fragment of a tap reads voxels 2x + dx for x = 0..7 of four y rows: with the parity split they are
 //     CONSECUTIVE 16-B slots, and the 20-slot pitch (y step = 40 slots = 8 mod 16) puts the four rows of a ds_read_b128
@@ -24,9 +23,14 @@
 //     x 8 voxels: whole 128-B lines of the channel-blocked output (common.h) without a transposition through LDS;
 //     sum x and sum x^2 per cout for Instance/GroupNorm as in the other kernels (quantised partials, common.h).
 // CW = couts per workgroup: 128 as above, or 64 (round 4: layers with Cout % 128 != 0, e.g. the 32 -> 64 conv of the base model's
-// level 1, which used to fall back to the register-staged kernel at 0.17 of the peak): the waves then split 2 x 4 - wave % 2
-// picks the 32-cout fragment, wave / 2 the output z plane (MF = 1) - over the SAME brick.
+// level 1, which used to fall back to the register-staged kernel at 0.17 of the peak): the waves then split 2 x 2 - wave & 1
+// picks the 32-cout fragment, wave >> 1 the output z planes {0, 1} or {2, 3} (MF = 2) - over the SAME brick.
 // The stride-2 convs read one input tensor (no virtual concat) and never carry the fused head.
+// Tried in round 5 and reverted: EIGHT waves per workgroup over the same brick (two per SIMD, 64 voxels x 32 couts each, 7 pieces
+// per wave and chunk) so that one wave's DMA issue, chunk barrier and epilogue run beside its partner's MFMAs - the reading of the
+// 0.42-busy matrix pipe as issue stalls.  Green on every test, and SLOWER: <true, 128> 751 against 860 TFLOP/s, <false, 64> 392
+// against 469 (same bench, boxes 6 % apart on the stride-1 kernels).  The pipe is not waiting for this wave's instruction
+// stream: a chunk's 52-KiB brick arrives in ~8 000 cycles whoever asks for it.
 #include "kernels.h"
 
 #include <cstdlib>
@@ -57,12 +61,9 @@ struct S2GeomH {
     static constexpr int IZ = 2 * TZ + 1, IY = 2 * TY + 1, IX = 2 * TX + 1;  // brick 9 x 9 x 17
     static constexpr int ROW = 20;                                      // 16-B slots per x row: even x at 0..8, odd x at 9..16
     static constexpr int PLANE_BLOCKS = 26;                             // 1-KiB DMA pieces per 8-channel plane (81 rows x 20 slots = 1620 <= 1664)
-    static constexpr int WAVES = 8;                                     // round 5: 512-thread workgroups, two waves per SIMD
-    static constexpr int KD = 7;                                        // pieces per wave and chunk: piece d = wave + 8 k of the buffer's 52 (+ 4 padding pieces)
-    static constexpr int BUF_BLOCKS = WAVES * KD;                       // 56: pieces 52 .. 55 fetch zeros into the tail of the buffer (every wave issues KD
-                                                                        // pieces: the hand-counted waits need the same number in flight in all waves)
-    static constexpr int PLANE_BYTES = PLANE_BLOCKS * 1024, BUF_BYTES = BUF_BLOCKS * 1024;
-    static constexpr int EVERY = 3;                                     // piece k goes out in tap 3 k
+    static constexpr int PLANE_BYTES = PLANE_BLOCKS * 1024, BUF_BYTES = 2 * PLANE_BYTES;
+    static constexpr int KD = 13;                                       // pieces per wave and chunk: piece d = wave + 4 k of the buffer's 52
+    static constexpr int EVERY = 2;                                     // piece k goes out in tap 2 k
     static constexpr int D = 9;                                         // weight ring depth in taps (divides 27)
     static constexpr bool dma_tap(int t) { return t % EVERY == 0 && t / EVERY < KD; }
     // vector-memory operations issued after the weight load of tap t (which went out at the end of tap t - D): one weight
@@ -77,29 +78,23 @@ struct S2GeomH {
     static constexpr int BIAS_OFF = 2 * BUF_BYTES;
     static constexpr size_t LDS_BYTES = (size_t)BIAS_OFF + 128 * 4;     // (the epilogue needs no LDS: stores by v_permlane32_swap)
     static_assert(IZ * IY * ROW <= PLANE_BLOCKS * 64, "plane does not hold the brick");
-    static_assert(EVERY * (KD - 1) <= 26 && WAVES * KD >= 2 * PLANE_BLOCKS, "piece schedule");
+    static_assert(EVERY * (KD - 1) <= 26 && 4 * KD == 2 * PLANE_BLOCKS, "piece schedule");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 template <bool STATS, int CW = 128>
-__global__ __launch_bounds__(512, 2) void conv3_f16_s2dma_kernel(S2ArgsH p) {
+__global__ __launch_bounds__(256, 1) void conv3_f16_s2dma_kernel(S2ArgsH p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     typedef S2GeomH G;
     static_assert(CW == 128 || CW == 64, "couts per workgroup");
-    // Round 5: eight waves per workgroup over the SAME double-buffered brick (one workgroup per CU: the brick takes 112 KiB).  With four
-    // waves - one per SIMD, 4 MFMAs per tap - every DMA piece (13 per wave and chunk, ~130 cycles of issue each), every chunk
-    // barrier and the epilogue stood in front of the wave's own MFMAs: matrix pipe 0.42 busy at a clock the chip held at 1.93 GHz,
-    // i.e. issue-bound, not power-bound.  Now two waves share a SIMD: NC = CW / 32 cout fragments x 8 / NC groups of output z planes,
-    // MF = 4 / groups voxel fragments per wave (2 for CW = 128, 1 for CW = 64), 7 pieces per wave and chunk; one wave's piece
-    // issue and epilogue run beside its partner's MFMAs.
-    constexpr int NC = CW / 32, ZG = G::WAVES / NC, MF = 4 / ZG;
+    constexpr int MF = CW == 128 ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *bias_lds = (float *)(lds_raw + G::BIAS_OFF);
     const int co_blk = (int)blockIdx.y * CW;
     if (tid < CW) bias_lds[tid] = p.bias[co_blk + tid];  // (published by the prologue's barrier)
-    const int wco = wave % NC;                              // this wave's 32-cout fragment of the workgroup's couts
-    const int wz = (wave / NC) * MF;                        // first output z plane of this wave's fragments
+    const int wco = CW == 128 ? wave : (wave & 1);          // this wave's 32-cout fragment of the workgroup's couts
+    const int wz = CW == 128 ? 0 : 2 * (wave >> 1);         // first output z plane of this wave's fragments
 
     // this workgroup's tile sequence: XCD group x owns the contiguous range [lo, hi); its workgroups stride through it
     const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
@@ -131,23 +126,23 @@ __global__ __launch_bounds__(512, 2) void conv3_f16_s2dma_kernel(S2ArgsH p) {
     unsigned dma_pk[G::KD];
 #pragma unroll
     for (int k = 0; k < G::KD; ++k) {
-        const int d = wave + G::WAVES * k;
+        const int d = wave + 4 * k;
         const int s = (d >= G::PLANE_BLOCKS ? d - G::PLANE_BLOCKS : d) * 64 + lane;
         const int row = s / G::ROW, c = s - row * G::ROW;
         const int bz = row / G::IY, by = row - bz * G::IY;
         const int bx = c < 9 ? 2 * c : 2 * (c - 9) + 1;
-        const bool valid = d < 2 * G::PLANE_BLOCKS && row < G::IZ * G::IY && c < G::IX;
+        const bool valid = row < G::IZ * G::IY && c < G::IX;
         const int face = (bz == 0) | ((by == 0) << 1) | ((bx == 0) << 2);
         dma_pk[k] = valid ? (unsigned)(((bz * p.Hi + by) * p.Wi + bx) | (face << 24)) : (8u << 24);
     }
     auto dma = [&](const TileCoord &tc, int faces, int ch, auto k_c, char *buf) {
         constexpr int k = decltype(k_c)::value;
-        const int d = wave + G::WAVES * k;  // (wave-uniform: scalar arithmetic; d >= 52: a padding piece, every lane reads the zero page)
+        const int d = wave + 4 * k;  // (wave-uniform: scalar arithmetic)
         // wave-uniform part: the brick origin voxel (may lie one voxel outside the tensor), this chunk's 16 channels, and
         // the 8-channel half of the piece's plane
         // (channel-blocked input, common.h: block 2 ch + plane of sample n; 16 B per voxel of a block)
         const long Vi = (long)p.Di * p.Hi * p.Wi;
-        const half_t *src = p.in + (((long)tc.n * (p.C >> 3) + 2 * ch + ((d >= G::PLANE_BLOCKS && d < 2 * G::PLANE_BLOCKS) ? 1 : 0)) * Vi +
+        const half_t *src = p.in + (((long)tc.n * (p.C >> 3) + 2 * ch + (d >= G::PLANE_BLOCKS ? 1 : 0)) * Vi +
                                     ((long)(2 * tc.oz0 - 1) * p.Hi + (2 * tc.oy0 - 1)) * p.Wi + (2 * tc.ox0 - 1)) * 8;
         unsigned pk = dma_pk[k];
         asm volatile("" : "+v"(pk));
@@ -164,8 +159,8 @@ __global__ __launch_bounds__(512, 2) void conv3_f16_s2dma_kernel(S2ArgsH p) {
     // LDS byte offset of this lane's voxel fragment 0 in a brick buffer, tap (0, 0, 0): output voxel (y = l31 >> 3, x = l31 & 7)
     // of plane z = mf reads input (2 z + dz, 2 y + dy, 2 x + dx) = row (2 z + dz) * 9 + 2 y + dy, slot x + (dx & 1) * 9 + (dx >> 1)
     const int a_lane = half * G::PLANE_BYTES + ((2 * (l31 >> 3)) * G::ROW + (l31 & 7)) * 16 + wz * G::MF_STRIDE;
-    // weights: cout block of 64 = 2 blockIdx.y + (wco >> 1) (CW = 128) or blockIdx.y (CW = 64), fragment nf = wco & 1 of the nf = 2 pack
-    const char *wblk = (const char *)(p.wp + (size_t)(CW == 128 ? 2 * blockIdx.y + (wco >> 1) : blockIdx.y) * p.nchunks * (27 * 2 * 512)) + (wco & 1) * 1024;
+    // weights: cout block of 64 = 2 blockIdx.y + (wave >> 1) (CW = 128) or blockIdx.y (CW = 64), fragment nf = wave & 1 of the nf = 2 pack
+    const char *wblk = (const char *)(p.wp + (size_t)(CW == 128 ? 2 * blockIdx.y + (wave >> 1) : blockIdx.y) * p.nchunks * (27 * 2 * 512)) + (wave & 1) * 1024;
     const unsigned wlane = lane * 16;
 #define S2_WLOAD(DST, SBASE) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(DST) : "v"(wl), "s"(SBASE) : "memory")
 #define S2_WWAIT(W, N) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(W) : "n"(N) : "memory")
@@ -367,7 +362,7 @@ int conv3d_f16_s2dma(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, c
             MI355_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
             attr_set[idx] = true;
         }
-        hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(64 * G::WAVES), G::LDS_BYTES, s, a);
+        hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), G::LDS_BYTES, s, a);
         MI355_HIP(hipGetLastError());
         return MI355_OK;
     };
