@@ -95,6 +95,58 @@ def _predict_folds_lanes(nets, data, lanes, patch_size, step_size, do_mirroring,
     return finish_sharded(total, parts[0][1], tuple(data.shape[1:]), patch_size, len(nets))
 
 
+def _n_items(nets, shape_zyx, patch_size, step_size):
+    from . import ops
+    return len(nets) * int(np.prod([len(ops.compute_steps(int(p), max(int(p), int(d)), float(step_size)))
+                                    for p, d in zip(patch_size, shape_zyx)]))
+
+
+def predict_members(members: Sequence[Sequence[UNet]], data, patch_size=(128, 128, 128), step_size=0.5, do_mirroring=True,
+                    mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid", batch_tiles=0, device="cuda", lanes=None):
+    """``[predict_folds(m, data, ...) for m in members]`` - the ensemble members of the reference's driver (:263-264: model 1, then
+    model 2) on one preprocessed volume - with the lanes STAGGERED: every lane takes its share of every member's (fold, tile) list,
+    but lane r starts with member r, so that at any time the lanes run different networks (or different depths of the same one)
+    instead of the same kernel sequence in lockstep, where both want the matrix cores at the same moments and both are in their
+    HBM-bound kernels at the same moments.  Results are those of ``predict_folds(lanes = ...)`` bit for bit (same per-lane item
+    lists, same lane-ordered sum)."""
+    import torch
+    members = [list(m) for m in members]
+    if not members or any(len(m) == 0 for m in members):
+        raise ValueError("no networks given")
+    data = _to_device(data, device)
+    lanes = default_lanes() if lanes is None else int(lanes)
+    _, z, y, x = data.shape
+    n_mirrors = 2 ** len(set(mirror_axes)) if do_mirroring else 1
+    ok = lanes > 1 and all(_n_items(m, (z, y, x), patch_size, step_size) * n_mirrors >= 32 * lanes for m in members)
+    if not ok or len(members) == 1:
+        return [predict_folds(m, data, patch_size, step_size, do_mirroring, mirror_axes, use_gaussian, nonlin, batch_tiles, device, lanes)
+                for m in members]
+    import os
+    stagger = 0 if os.environ.get("MI355_LANE_STAGGER", "1") == "0" else 1   # (0: every lane takes the members in the same order - the A/B switch)
+    cur = torch.cuda.current_stream(data.device)
+    ready = cur.record_event()
+    parts = [[None] * lanes for _ in members]
+    for r, st in enumerate(_lane_streams(data.device, lanes)):
+        st.wait_event(ready)
+        with torch.cuda.stream(st):
+            for k in range(len(members)):
+                mi = (r * stagger + k) % len(members)
+                parts[mi][r] = predict_tile_sharded(members[mi], data, r, lanes, patch_size, step_size, do_mirroring, mirror_axes,
+                                                    use_gaussian, nonlin, batch_tiles, data.device, want_cnt=(r == 0))
+        for mi in range(len(members)):
+            for t in parts[mi][r]:
+                if t is not None:
+                    t.record_stream(cur)
+        cur.wait_stream(st)
+    out = []
+    for mi, m in enumerate(members):
+        total = parts[mi][0][0]
+        for agg, _ in parts[mi][1:]:
+            total += agg
+        out.append(finish_sharded(total, parts[mi][0][1], (z, y, x), patch_size, len(m)))
+    return out
+
+
 def predict_folds(nets: Sequence[UNet], data, patch_size=(128, 128, 128), step_size=0.5, do_mirroring=True,
                   mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid", batch_tiles=0, device="cuda", lanes=None):
     """Class probabilities ``[K, Z, Y, X]`` (CUDA fp32) of one preprocessed ``[C, Z, Y, X]`` volume,
@@ -109,9 +161,7 @@ def predict_folds(nets: Sequence[UNet], data, patch_size=(128, 128, 128), step_s
     _, z, y, x = data.shape
     lanes = default_lanes() if lanes is None else int(lanes)
     if lanes > 1:
-        from . import ops
-        n_items = len(nets) * int(np.prod([len(ops.compute_steps(int(p), max(int(p), int(d)), float(step_size)))
-                                           for p, d in zip(patch_size, (z, y, x))]))
+        n_items = _n_items(nets, (z, y, x), patch_size, step_size)
         # (the split pays when every lane still runs full forward batches - 32 samples = (tile, mirror) pairs per lane; measured:
         #  config 3 fp16, 8 tiles x 8 mirrors per member: 273 -> 266 ms with two lanes, 272 with three; config 2, 8 tiles without
         #  mirrors: 28.3 ms either way, so it stays on one lane and bit-identical with mi355_sw_predict)

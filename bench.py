@@ -404,14 +404,11 @@ def run_single_volume(ctx, args, config, dtype, steps, warmup, data, props, step
     flops_per_volume = sum(n.flops(PATCH) for n in nets) * n_tiles * n_mirrors
 
     def step():
-        segs = []
-        for fold_nets in members:
-            if tiles_mode:   # partitioning B: this rank's (fold, tile) items, ONE exchange per member, identical result on every rank
-                probs = parallel.predict_case_tile_sharded(fold_nets, data, PATCH, 0.5, wl["tta"], (0, 1, 2), True, "sigmoid")
-            else:
-                probs = predictor.predict_folds(fold_nets, data, PATCH, 0.5, wl["tta"], (0, 1, 2), True, "sigmoid",
-                                                batch_tiles=args.batch_tiles)
-            segs.append(ops.regions_to_labels(probs, (1, 2, 3), lo, full))
+        if tiles_mode:   # partitioning B: this rank's (fold, tile) items, ONE exchange per member, identical result on every rank
+            all_probs = [parallel.predict_case_tile_sharded(fold_nets, data, PATCH, 0.5, wl["tta"], (0, 1, 2), True, "sigmoid") for fold_nets in members]
+        else:            # (the ensemble members of one case: the lanes of predictor.predict_members take them in staggered order)
+            all_probs = predictor.predict_members(members, data, PATCH, 0.5, wl["tta"], (0, 1, 2), True, "sigmoid", batch_tiles=args.batch_tiles)
+        segs = [ops.regions_to_labels(probs, (1, 2, 3), lo, full) for probs in all_probs]
         return segs[0] if len(segs) == 1 else ops.label_ensemble(segs[0], segs[1])
 
     elapsed, prof, seg = timed_region(ctx, step, steps, warmup, nets)
@@ -464,10 +461,8 @@ def run_reference_setting(ctx, dtype, data, props, steps_tbl, oracle=None, steps
     flops = sum(n.flops(PATCH) for folds in nets for n in folds) * n_tiles * 8
 
     def step():
-        segs = []
-        for folds in nets:
-            probs = predictor.predict_folds(folds, data, PATCH, 0.5, True, (0, 1, 2), True, "sigmoid")
-            segs.append(ops.regions_to_labels(probs, (1, 2, 3), lo, full))
+        segs = [ops.regions_to_labels(probs, (1, 2, 3), lo, full)
+                for probs in predictor.predict_members(nets, data, PATCH, 0.5, True, (0, 1, 2), True, "sigmoid")]
         return ops.label_ensemble(segs[0], segs[1])
 
     step()
