@@ -104,11 +104,10 @@ def _n_items(nets, shape_zyx, patch_size, step_size):
 def predict_members(members: Sequence[Sequence[UNet]], data, patch_size=(128, 128, 128), step_size=0.5, do_mirroring=True,
                     mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid", batch_tiles=0, device="cuda", lanes=None):
     """``[predict_folds(m, data, ...) for m in members]`` - the ensemble members of the reference's driver (:263-264: model 1, then
-    model 2) on one preprocessed volume - with the lanes STAGGERED: every lane takes its share of every member's (fold, tile) list,
-    but lane r starts with member r, so that at any time the lanes run different networks (or different depths of the same one)
-    instead of the same kernel sequence in lockstep, where both want the matrix cores at the same moments and both are in their
-    HBM-bound kernels at the same moments.  Results are those of ``predict_folds(lanes = ...)`` bit for bit (same per-lane item
-    lists, same lane-ordered sum)."""
+    model 2) on one preprocessed volume - with ALL members' work enqueued on the lanes before the caller's stream joins them (one
+    join per case instead of one per member): every lane takes its share of every member's (fold, tile) list.  Optionally
+    staggered (lane r starts with member r; measured neutral, see below).  Results are those of ``predict_folds(lanes = ...)`` bit
+    for bit (same per-lane item lists, same lane-ordered sum)."""
     import torch
     members = [list(m) for m in members]
     if not members or any(len(m) == 0 for m in members):
@@ -122,7 +121,10 @@ def predict_members(members: Sequence[Sequence[UNet]], data, patch_size=(128, 12
         return [predict_folds(m, data, patch_size, step_size, do_mirroring, mirror_axes, use_gaussian, nonlin, batch_tiles, device, lanes)
                 for m in members]
     import os
-    stagger = 0 if os.environ.get("MI355_LANE_STAGGER", "1") == "0" else 1   # (0: every lane takes the members in the same order - the A/B switch)
+    # (MI355_LANE_STAGGER=1: lane r starts with member r.  Measured on config 3 fp16, alternating runs on one box: 267.3 / 268.0 ms
+    #  without, 268.9 / 268.4 with, 271.3 on one lane (profiles/r05_lanes_stagger_ab.txt) - the lanes drift apart by themselves;
+    #  off by default)
+    stagger = 1 if os.environ.get("MI355_LANE_STAGGER", "0") == "1" else 0
     cur = torch.cuda.current_stream(data.device)
     ready = cur.record_event()
     parts = [[None] * lanes for _ in members]

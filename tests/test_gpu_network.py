@@ -213,6 +213,42 @@ def test_fold_list_tile_sharding(amd, gpu):
         n.close()
 
 
+def test_lanes_agree_with_the_single_stream_path(amd, gpu):
+    """Round 5: predict_folds / predict_members over two (three) HIP streams of one GPU - the library keeps an activation arena and
+    scratch per stream - against the single-stream mi355_sw_predict: 2 folds x 2x2x2 tiles x 8 mirrors = 128 samples (enough
+    for the sample rule of the lane split), fp32.  The lane-ordered sum of the partial aggregates differs from the in-order sum
+    by fp32 rounding only; predict_members (staggered member order) equals per-member predict_folds on lanes bit for bit; two
+    DIFFERENT networks run on two user streams at once and give what they give one after the other."""
+    sds = [_small_net(amd, seed=s) for s in (21, 22)]
+    nets = [amd.UNet(sd, norm="batch") for sd in sds]
+    other = [amd.UNet(_small_net(amd, seed=s), norm="batch") for s in (23, 24)]
+    patch = (32, 32, 32)
+    vol = torch.from_numpy(np.random.RandomState(8).standard_normal((4, 40, 48, 36)).astype(np.float32)).to(gpu)
+    one = amd.predictor.predict_folds(nets, vol, patch, lanes=1)
+    for lanes in (2, 3):
+        got = amd.predictor.predict_folds(nets, vol, patch, lanes=lanes)
+        assert float((got - one).abs().max()) <= 2e-6, lanes
+    both = amd.predictor.predict_members([nets, other], vol, patch, lanes=2)
+    assert torch.equal(both[0], amd.predictor.predict_folds(nets, vol, patch, lanes=2))
+    assert torch.equal(both[1], amd.predictor.predict_folds(other, vol, patch, lanes=2))
+    # two user streams, one network each, enqueued back to back: separate arenas, no interference
+    want = [amd.predictor.predict_folds(n, vol, patch, lanes=1) for n in (nets, other)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None, None]
+    for _ in range(3):
+        for i, (st, n) in enumerate(zip(streams, (nets, other))):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs[i] = amd.predictor.predict_folds(n, vol, patch, lanes=1)
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], want[0]) and torch.equal(outs[1], want[1])
+    for n in nets + other:
+        n.close()
+
+
 # --------------------------------------------------------------------------- fp16 storage (BASELINE configs[2])
 # Tolerance for the fp16 path, stated here as the north_star asks: activations are rounded to fp16 (2^-11 relative)
 # after every block, accumulation stays fp32.  Against the fp32 CPU oracle we require the north_star's gate, Dice >= 0.999
@@ -523,6 +559,11 @@ def test_five_fold_mean_at_full_patch(amd, gpu, tile128):
         assert err <= tol and d_sure["mean"] >= 0.9999
         if dtype == "f32":
             assert d["mean"] >= 0.9999
+        else:
+            # numeric floor for the all-voxel figure: this seed set reads 0.998977; over 5 weight-seed sets x 2 noise
+            # tiles the setting ranges 0.99898 - 0.99995 (profiles/r05_f16_seed_study_noise_tiles.txt: noise tiles are the
+            # ill-conditioned case - on brain tiles the same setting never reads below 0.99941).  0.9985 = the minimum - 5e-4.
+            assert d["mean"] >= 0.9985
         for n in nets:
             n.close()
 

@@ -5,7 +5,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out/prof_$1; mkdir -p $O
-B="python3 $R/bench.py --no-secondary --no-cpu-baseline"
+B="python3 $R/bench.py --no-secondary --no-cpu-baseline --lanes 1"   # (one lane: per-kernel durations and counters of kernels that do not overlap)
 run() { name=$1; shift; echo "== $name"; "$@" > $O/$name.log 2>&1; }
 run stats_f32   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -o t -- $B --steps 10 --warmup 2
 run stats_c2f16 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2f16 -o t -- $B --config 2 --dtype f16 --steps 10 --warmup 2
