@@ -24,7 +24,7 @@ import subprocess
 
 # kernels whose vmcnt waits are counted by hand (name prefixes of the demangled kernel)
 HAND_COUNTED = ("conv3_f32_wino3_kernel", "conv3_f32_wino2_kernel", "conv3_f32_wino_kernel", "conv3_f32_s2dma_kernel",
-                "conv3_f16_dma_kernel", "conv3_f16_dma2_kernel", "conv3_f16_s2dma_kernel", "conv3_f16_c32_kernel")
+                "conv3_f16_dma_kernel", "conv3_f16_s2dma_kernel", "conv3_f16_c32_kernel")
 
 VMEM = re.compile(r"^\s*(global_|buffer_|flat_|scratch_)")
 SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")

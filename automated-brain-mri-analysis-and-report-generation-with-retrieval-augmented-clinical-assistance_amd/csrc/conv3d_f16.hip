@@ -715,8 +715,7 @@ struct DmaGeomH {
     static constexpr bool INTERLEAVED = false;
     static constexpr int VOX_BYTES = 16;
     static constexpr int NF = NF_;  // 32-cout fragments per wave: 2 = conv3_f16_dma_kernel (64 couts per workgroup), 1 = conv3_f16_c32_kernel
-    static constexpr int D = D_;   // weight ring depth in taps (divides 27: the ring phase is the same in every chunk); 9, or 3 where two
-                                   // workgroups share a CU with 128 accumulators each (conv3_f16_dma2_kernel: 256 registers per wave)
+    static constexpr int D = D_;   // weight ring depth in taps (divides 27: the ring phase is the same in every chunk)
     static constexpr int KD = 8;   // DMAs per wave and chunk: range wave + 4 (k & 3) of plane k >> 2
     static constexpr int EVERY = EVERY_;  // DMA k goes out in tap EVERY * k: four waves issuing 64-line DMAs in the same tap ask the
                                           // L1 for more lines than a tap has cycles (stamps: +1.3-2.2k cycles per chunk at EVERY = 1)
@@ -736,7 +735,7 @@ struct DmaGeomH {
     // while this one ran, and capped the tables at 19 KiB: the 256- and 512-channel levels fell back to the register-staged kernel.)
     static constexpr int BIAS_OFF = 2 * BUF_BYTES, JUNK_OFF = BIAS_OFF + 64 * 4, TAB_OFF = JUNK_OFF + 1024;
     static constexpr size_t LDS_BYTES = (size_t)JUNK_OFF;
-    static constexpr int WG_PER_CU = (NF == 1 || D_ == 3) ? 2 : 1;   // (NF = 1: 64 accumulators per wave, two waves per SIMD)
+    static constexpr int WG_PER_CU = NF == 1 ? 2 : 1;   // (NF = 1: 64 accumulators per wave, two waves per SIMD)
     static constexpr int TAB_MAX_BYTES = 160 * 1024 / WG_PER_CU - TAB_OFF;
     // INAFF: piece k (DMA in tap EVERY k) has landed once the weights of tap EVERY k + 10 have been waited for (they were
     // issued after it); it is read back in that tap and normalised + written in the next one (NF = 1: in the next two)
@@ -1268,13 +1267,11 @@ __global__ __launch_bounds__(256, 1) void conv3_f16_dma_kernel(ConvArgsH p) {
     conv3_f16_dma_body<STATS, INAFF, 2, false>(p);
 }
 
-// Experiment (round 5, MI355_F16_DMA2=1): 64 couts per workgroup with a three-tap weight ring, so that a wave fits 256 registers and TWO
-// workgroups share a CU - the epilogue, chunk barrier and DMA issue of one beside the MFMAs of the other.
-template <bool STATS, bool INAFF = false>
-__global__ __launch_bounds__(256, 2) void conv3_f16_dma2_kernel(ConvArgsH p) {
-    conv3_f16_dma_body<STATS, INAFF, 2, false, 3>(p);
-}
-
+// Measured in round 5 and removed: the 64-cout body with a THREE-tap weight ring (211 - 225 registers per wave, no spills) and two
+// workgroups per CU, so that the epilogue, chunk barrier and DMA issue of one run beside the MFMAs of the other: 1 318 against
+// 1 320 TFLOP/s on <true, false>, 1 220 - 1 234 against 1 224 on <true, true>, config 3 fp16 264.0 / 263.8 against 264.5 / 264.7 ms
+// in alternating runs on one box (profiles/r05_dma2_ab.txt).  These launches run at the board's power limit: a fuller matrix
+// pipe is paid back in clock.
 // Cout = 32 (round 5): the same body with ONE cout fragment per wave - 64 accumulators per lane, so TWO workgroups per CU (two
 // waves per SIMD): a wave's DMA issue stalls, its chunk barrier and its epilogue run beside the other workgroup's MFMAs.  With
 // half the MFMAs per brick a single workgroup per CU could not hide them (every DMA costs the wave ~130 cycles of issue; the
@@ -1501,22 +1498,6 @@ int conv3d_mfma_f16(const ConvWeightsH &w, const ConvCallH &c, hipStream_t s, co
                 if (kernel_name) *kernel_name = c.stats ? "conv3_f16_c32_kernel<true, false, false>" : "conv3_f16_c32_kernel<false, false, false>";
                 if (c.stats) return launch_h(conv3_f16_c32_kernel<true>, b, dim3(gx, gy), lds_plain, s, &attr_c32[0]);
                 return launch_h(conv3_f16_c32_kernel<false>, b, dim3(gx, gy), lds_plain, s, &attr_c32[1]);
-            }
-            static int dma2 = -1;
-            if (dma2 < 0) { const char *e = getenv("MI355_F16_DMA2"); dma2 = (e && e[0] == '1') ? 1 : 0; }
-            if (dma2 && tiles * gy >= 512 && (!c.in_scale || tab_bytes <= (size_t)DmaGeomH<2, 2, 3>::TAB_MAX_BYTES)) {
-                static size_t attr_d2[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
-                int gx2 = 512 / gy;
-                gx2 = gx2 < 8 ? 8 : (gx2 / 8) * 8;
-                if (gx2 > need) gx2 = need;
-                if (c.in_scale) {
-                    if (kernel_name) *kernel_name = c.stats ? "conv3_f16_dma2_kernel<true, true>" : "conv3_f16_dma2_kernel<false, true>";
-                    if (c.stats) return launch_h(conv3_f16_dma2_kernel<true, true>, b, dim3(gx2, gy), lds_aff, s, &attr_d2[2]);
-                    return launch_h(conv3_f16_dma2_kernel<false, true>, b, dim3(gx2, gy), lds_aff, s, &attr_d2[3]);
-                }
-                if (kernel_name) *kernel_name = c.stats ? "conv3_f16_dma2_kernel<true, false>" : "conv3_f16_dma2_kernel<false, false>";
-                if (c.stats) return launch_h(conv3_f16_dma2_kernel<true>, b, dim3(gx2, gy), lds_plain, s, &attr_d2[0]);
-                return launch_h(conv3_f16_dma2_kernel<false>, b, dim3(gx2, gy), lds_plain, s, &attr_d2[1]);
             }
             static size_t attr_dma[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
             if (c.in_scale) {
