@@ -93,6 +93,14 @@ def load():
         except Exception as e:  # no hipcc on this machine: say so instead of silently running the old library
             import warnings
             warnings.warn(f"{path} was built from a different csrc/ and could not be rebuilt ({e}); running the stale library")
+    # torch first: its wheel bundles a HIP runtime of its own (torch/lib/libamdhip64.so), and the library must share THAT runtime -
+    # it is handed torch's device pointers and streams.  Loaded before torch, this library pulls in /opt/rocm's libamdhip64 under
+    # the same SONAME and the process ends up with one runtime torch was not built against (seen in round 5: build() + smoke() in
+    # one process - mi355_device_count() = 0 on a box with a GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(path))
     vp = C.c_void_p
     lib.mi355_last_error.restype = C.c_char_p
