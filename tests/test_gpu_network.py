@@ -245,6 +245,15 @@ def test_lanes_agree_with_the_single_stream_path(amd, gpu):
             torch.cuda.current_stream().wait_stream(st)
         torch.cuda.synchronize()
         assert torch.equal(outs[0], want[0]) and torch.equal(outs[1], want[1])
+    # more streams than the library has lanes (4): the sixth takes over the least recently used lane after a device synchronise
+    for k in range(6):
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            got = amd.predictor.predict_folds(nets if k % 2 == 0 else other, vol, patch, lanes=1)
+        torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want[k % 2]), k
     for n in nets + other:
         n.close()
 
