@@ -153,7 +153,7 @@ def predict_folds(nets: Sequence[UNet], data, patch_size=(128, 128, 128), step_s
                   mirror_axes=(0, 1, 2), use_gaussian=True, nonlin="sigmoid", batch_tiles=0, device="cuda", lanes=None):
     """Class probabilities ``[K, Z, Y, X]`` (CUDA fp32) of one preprocessed ``[C, Z, Y, X]`` volume,
     averaged over ``nets`` (the fold ensemble of driver :95-128).  ``lanes`` (default ``MI355_LANES``, 2): number of HIP streams
-    the work list is spread over when it has at least that many (fold, tile) items; 1 = one ``mi355_sw_predict`` call."""
+    the work list is spread over when every lane still gets 32 (tile, mirror) samples; otherwise, and with 1, one ``mi355_sw_predict`` call."""
     import torch
     if len(nets) == 0:
         raise ValueError("no networks given")
