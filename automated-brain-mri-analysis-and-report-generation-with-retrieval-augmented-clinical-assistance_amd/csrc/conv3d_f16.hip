@@ -776,6 +776,9 @@ __device__ __forceinline__ void conv3_f16_dma_body(const ConvArgsH &p) {
     const int hi = lo + q8 + (xcd < r8 ? 1 : 0);
     int tile = lo + li;
     if (tile >= hi) return;
+    // (Measured in round 5 and removed: starting the second half of the Cout = 32 grid - the CUs' second workgroups - half a chunk late,
+    //  MI355X_MICROARCH.md "Two waves per SIMD" item 9: s_sleep 40 / 80 / 127 against none, tools/h16_probe c: no difference beyond
+    //  the +-4 % between repeats, profiles/r05_c32_stagger.txt.  The two workgroups of a CU drift apart by themselves.)
 
     struct TileCoord { int n, oz0, oy0, ox0; };
     auto decode = [&](int t) {
