@@ -820,8 +820,15 @@ __device__ __forceinline__ void conv3_f16_dma_body(const ConvArgsH &p) {
         unsigned pk = dma_pk[k & 3];
         asm volatile("" : "+v"(pk));
         bool inside = (pk & ((unsigned)(faces | 64) << 24)) == 0;
+#if defined(MI355_H16_ABL_DMA) && MI355_H16_ABL_DMA == 1   // (probe only: every piece reads the 16-B zero page - the same instructions, nothing fetched from beyond the L1; results wrong)
+        inside = false;
+#endif
         unsigned off = (pk & 0xffffffu) << 4;  // bytes: 16 per voxel of a block (< 2^32: host check)
+#if defined(MI355_H16_ABL_DMA) && MI355_H16_ABL_DMA == 2   // (probe only: real data, but every piece comes from the first 256 KiB of the tensor - L2-resident; results wrong.
+        const char *gin = (const char *)p.in0 + (off & 0x3fff0u);   //  Based at the TENSOR, not at the brick origin, which may lie in front of it)
+#else
         const char *gin = (const char *)src + off;
+#endif
         asm volatile("" : "+v"(gin));  // (computed for every lane: left to itself the compiler branches around it, and a basic-block
                                        //  boundary between the MFMAs of a tap makes it wait for every outstanding LDS read there)
         const char *g = inside ? gin : (const char *)p.zeros;  // the zero page holds both planes' pieces

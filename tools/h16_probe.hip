@@ -76,6 +76,11 @@ static int run(int N, int D, int cin, int cout, int reps, bool inaff = false, bo
 
 int main(int argc, char **argv) {
     setvbuf(stdout, nullptr, _IOLBF, 0);
+    if (argc > 1 && argv[1][0] == 'a') {  // ablation pairs: one Cout = 32 shape, one Cout = 64 shape (build with -DMI355_H16_ABL_DMA / -DMI355_H16_ABL_W)
+        if (run(8, 128, 64, 32, 3)) return 1;
+        if (run(8, 128, 64, 64, 3)) return 1;
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'c') {  // the Cout = 32 layers of the full-resolution level (conv3_f16_c32_kernel, round 5)
         if (run(8, 128, 32, 32, 3)) return 1;
         if (run(8, 128, 64, 32, 3)) return 1;
